@@ -1,0 +1,156 @@
+/* pointnet_refine_hip.h - C ABI of the MI355X (gfx950) LineRefineNet hot-path library.
+ *
+ * The reference (1pathplanningzzj/pointnet_refine) has no FFI or plugin interface:
+ * its hot path is the Python nn.Module surface of src/model.py.  This library is the
+ * native layer the replacement nn.Modules (pointnet_refine_amd/model.py) call through
+ * ctypes.  Every entry point below names the reference code it replaces.
+ *
+ * Conventions
+ *  - all tensors are fp32, POINT-MAJOR: rows = B*N points, columns = channels,
+ *    row-major with the stated leading dimension;
+ *  - every pointer is DEVICE memory owned by the caller (PyTorch); the library
+ *    allocates nothing, keeps no pointer after return and launches only on `stream`;
+ *  - return 0 on success, a negative code otherwise; prh_last_error() gives the text
+ *    (thread-local);
+ *  - re-entrant; the autograd engine calls the backward entry points from its own
+ *    thread, so each call sets the device from `device` before launching.
+ */
+#ifndef POINTNET_REFINE_HIP_H
+#define POINTNET_REFINE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PRH_OK 0
+#define PRH_ERR_ARG (-1)
+#define PRH_ERR_WORKSPACE (-2)
+#define PRH_ERR_HIP (-3)
+
+#define PRH_MAX_LAYERS 8
+
+/* One shared-MLP layer: 1x1 Conv1d (= Linear over points) + BatchNorm1d (+ ReLU).
+ * Reference: nn.Conv1d/nn.BatchNorm1d pairs of src/model.py:10-20 (encoder),
+ * :23-27 (fusion), :150-159 (point_mlp). */
+typedef struct {
+  const float* w;        /* [cout, cin]  (Conv1d weight (cout,cin,1) viewed 2-D) */
+  const float* b;        /* [cout] */
+  const float* gamma;    /* [cout] BatchNorm weight */
+  const float* beta;     /* [cout] BatchNorm bias */
+  float* running_mean;   /* [cout] updated in train mode */
+  float* running_var;    /* [cout] updated in train mode (unbiased variance) */
+  int64_t* num_batches_tracked; /* scalar, +1 in train mode; may be NULL */
+  int cin, cout;
+} prh_bn_layer;
+
+/* Gradients of one shared-MLP layer (any pointer may be NULL = not wanted). */
+typedef struct {
+  float* dw;      /* [cout, cin] */
+  float* db;      /* [cout] */
+  float* dgamma;  /* [cout] */
+  float* dbeta;   /* [cout] */
+} prh_bn_layer_grad;
+
+/* MultiScalePointNetEncoder parameters, src/model.py:7-37. */
+typedef struct {
+  int in_channel;          /* C (4 in LineRefineNet; any C>=4 for the bare encoder) */
+  int out_dim;             /* 1024 */
+  prh_bn_layer conv[5];    /* conv1..5 + bn1..5 */
+  prh_bn_layer fusion;     /* fusion.0 (cin = 64+128+256+512+out_dim) + fusion.1 */
+  const float* gate_w1;    /* intensity_gate.0.weight [64] (Conv1d(1,64,1)) */
+  const float* gate_b1;    /* [64] */
+  const float* gate_w2;    /* intensity_gate.2.weight [out_dim, 64] */
+  const float* gate_b2;    /* [out_dim] */
+} prh_encoder_params;
+
+typedef struct {
+  prh_bn_layer_grad conv[5];
+  prh_bn_layer_grad fusion;
+  float* d_gate_w1; float* d_gate_b1; float* d_gate_w2; float* d_gate_b2;
+} prh_encoder_grads;
+
+/* Activations the forward keeps for the backward (caller-allocated).
+ *   cat = 64+128+256+512+out_dim                                            */
+typedef struct {
+  float* z_cat;      /* [P, cat]      pre-BN outputs of conv1..5, concatenated by column */
+  float* z_fus;      /* [P, out_dim]  pre-BN output of the fusion conv */
+  float* gate;       /* [P, out_dim]  0.5+0.5*sigmoid(.) ; may be NULL when no backward */
+  float* bn_scale;   /* [cat+out_dim] gamma*rstd            (BN as y = z*scale+shift) */
+  float* bn_shift;   /* [cat+out_dim] beta - mean*scale */
+  float* bn_mean;    /* [cat+out_dim] */
+  float* bn_rstd;    /* [cat+out_dim] */
+  int32_t* argmax;   /* [B, out_dim]  first arg-max point of the max-pool; NULL = skip */
+} prh_encoder_saved;
+
+/* Bytes of scratch the encoder entry points need for P = B*N points
+ * (backward = 0: prh_encoder_forward only; 1: also prh_encoder_backward). */
+size_t prh_encoder_workspace_bytes(int B, int N, int in_channel, int out_dim, int backward);
+
+/* MultiScalePointNetEncoder.forward, src/model.py:39-62.
+ *   ctx      [B,N,C] point-major (the reference takes the (B,C,N) transpose view)
+ *   fused    [B,N,out_dim]          (reference returns its (B,out_dim,N) transpose)
+ *   gfeat    [B,2*out_dim] = [max over N | mean over N]; NULL = skip pooling
+ *   training 1: batch statistics + running-stat update, 0: running statistics */
+int prh_encoder_forward(const prh_encoder_params* prm, const float* ctx, int B, int N,
+                        int training, float momentum, float eps,
+                        float* fused, float* gfeat, const prh_encoder_saved* saved,
+                        void* workspace, size_t workspace_bytes, int device, void* stream);
+
+/* Backward of the above (autograd of src/model.py:39-62).
+ *   d_fused [B,N,out_dim] or NULL, d_gfeat [B,2*out_dim] or NULL (at least one)
+ *   d_ctx   [B,N,C] or NULL
+ *   training must equal the forward's flag.
+ * d_fused is used as scratch and is overwritten. */
+int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B, int N,
+                         int training, float* d_fused, const float* d_gfeat,
+                         const prh_encoder_saved* saved, const prh_encoder_grads* grads,
+                         float* d_ctx, void* workspace, size_t workspace_bytes, int device,
+                         void* stream);
+
+/* nn.Linear forward y = act(x W^T + b): context_proj (src/model.py:147,194) and any
+ * other Linear on the path.  x [rows,k] (ld ldx), w [n,k], y [rows,n]; relu: 0/1.
+ * k and ldx must be multiples of 4. */
+int prh_linear_forward(const float* x, long ldx, const float* w, const float* b, float* y,
+                       int rows, int k, int n, int relu, int device, void* stream);
+
+/* nn.Linear backward: dx = dy W (NULL = skip), dw = dy^T x, db = colsum(dy).
+ * n and k multiples of 4. */
+size_t prh_linear_backward_workspace_bytes(int rows, int k, int n);
+int prh_linear_backward(const float* x, long ldx, const float* w, const float* dy, float* dx,
+                        float* dw, float* db, int rows, int k, int n, void* workspace,
+                        size_t workspace_bytes, int device, void* stream);
+
+/* Stack of <= PRH_MAX_LAYERS shared-MLP layers applied to x [P,cin0]:
+ * LineRefineNet.point_mlp, src/model.py:150-159,200-201 (relu_last = 0).
+ *   z_cat [P, sum(cout)] pre-BN outputs (kept for backward), y [P, cout_last]. */
+size_t prh_mlp_stack_workspace_bytes(int P, int n_layers, const prh_bn_layer* layers);
+int prh_mlp_stack_forward(const prh_bn_layer* layers, int n_layers, int relu_last,
+                          const float* x, int P, int training, float momentum, float eps,
+                          float* z_cat, float* y, float* bn_scale, float* bn_shift,
+                          float* bn_mean, float* bn_rstd, void* workspace,
+                          size_t workspace_bytes, int device, void* stream);
+int prh_mlp_stack_backward(const prh_bn_layer* layers, int n_layers, int relu_last,
+                           const float* x, int P, int training, const float* dy,
+                           const float* z_cat, const float* bn_scale, const float* bn_shift,
+                           const float* bn_mean, const float* bn_rstd,
+                           const prh_bn_layer_grad* grads, float* dx, void* workspace,
+                           size_t workspace_bytes, int device, void* stream);
+
+/* Raw GEMM cores, exported for the unit tests (tests/test_gemm_gpu.py).
+ *   nt: c[m,n] = a[m,k] w[n,k]^T     tn: c[mo,ni] = a[p,mo]^T b[p,ni]          */
+int prh_test_gemm_nt(const float* a, const float* w, float* c, int m, int n, int k,
+                     int device, void* stream);
+size_t prh_test_gemm_tn_workspace_bytes(int p, int mo, int ni);
+int prh_test_gemm_tn(const float* a, const float* b, float* c, float* colsum, int p, int mo,
+                     int ni, void* workspace, size_t workspace_bytes, int device, void* stream);
+
+const char* prh_last_error(void);
+const char* prh_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

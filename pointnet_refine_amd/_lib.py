@@ -1,0 +1,137 @@
+"""Loader and ctypes bindings for ``libpointnet_refine_hip.so`` (C ABI declared in
+``include/pointnet_refine_hip.h``).
+
+The product path has NO CPU fallback: ``lib()`` raises if the library is missing, and
+every op in ``ops.py`` raises on non-GPU tensors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "libpointnet_refine_hip.so")
+_SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("prh_lib.hip", "prh_gemm.hpp", "prh_kernels.hpp")]
+_HEADER = os.path.join(_ROOT, "include", "pointnet_refine_hip.h")
+
+PRH_MAX_LAYERS = 8
+
+
+class BnLayer(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
+                ("num_batches_tracked", C.c_void_p), ("cin", C.c_int), ("cout", C.c_int)]
+
+
+class BnLayerGrad(C.Structure):
+    _fields_ = [("dw", C.c_void_p), ("db", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p)]
+
+
+class EncoderParams(C.Structure):
+    _fields_ = [("in_channel", C.c_int), ("out_dim", C.c_int), ("conv", BnLayer * 5),
+                ("fusion", BnLayer), ("gate_w1", C.c_void_p), ("gate_b1", C.c_void_p),
+                ("gate_w2", C.c_void_p), ("gate_b2", C.c_void_p)]
+
+
+class EncoderGrads(C.Structure):
+    _fields_ = [("conv", BnLayerGrad * 5), ("fusion", BnLayerGrad), ("d_gate_w1", C.c_void_p),
+                ("d_gate_b1", C.c_void_p), ("d_gate_w2", C.c_void_p), ("d_gate_b2", C.c_void_p)]
+
+
+class EncoderSaved(C.Structure):
+    _fields_ = [("z_cat", C.c_void_p), ("z_fus", C.c_void_p), ("gate", C.c_void_p),
+                ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p), ("bn_mean", C.c_void_p),
+                ("bn_rstd", C.c_void_p), ("argmax", C.c_void_p)]
+
+
+EXPORTS = [
+    "prh_encoder_workspace_bytes", "prh_encoder_forward", "prh_encoder_backward",
+    "prh_linear_forward", "prh_linear_backward_workspace_bytes", "prh_linear_backward",
+    "prh_mlp_stack_workspace_bytes", "prh_mlp_stack_forward", "prh_mlp_stack_backward",
+    "prh_test_gemm_nt", "prh_test_gemm_tn_workspace_bytes", "prh_test_gemm_tn",
+    "prh_last_error", "prh_version",
+]
+
+_lock = threading.Lock()
+_lib = None
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.exists(s) and os.path.getmtime(s) > t for s in _SOURCES + [_HEADER])
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP library for gfx950 in-tree with hipcc (cross-compiles without a GPU)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+           "-o", LIB_PATH, _SOURCES[0]]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+def _bind(lib):
+    vp, i, f, sz, lg = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_long
+    lib.prh_last_error.restype = C.c_char_p
+    lib.prh_version.restype = C.c_char_p
+    lib.prh_encoder_workspace_bytes.restype = sz
+    lib.prh_encoder_workspace_bytes.argtypes = [i, i, i, i, i]
+    lib.prh_encoder_forward.restype = i
+    lib.prh_encoder_forward.argtypes = [C.POINTER(EncoderParams), vp, i, i, i, f, f, vp, vp,
+                                        C.POINTER(EncoderSaved), vp, sz, i, vp]
+    lib.prh_encoder_backward.restype = i
+    lib.prh_encoder_backward.argtypes = [C.POINTER(EncoderParams), vp, i, i, i, vp, vp,
+                                         C.POINTER(EncoderSaved), C.POINTER(EncoderGrads), vp, vp,
+                                         sz, i, vp]
+    lib.prh_linear_forward.restype = i
+    lib.prh_linear_forward.argtypes = [vp, lg, vp, vp, vp, i, i, i, i, i, vp]
+    lib.prh_linear_backward_workspace_bytes.restype = sz
+    lib.prh_linear_backward_workspace_bytes.argtypes = [i, i, i]
+    lib.prh_linear_backward.restype = i
+    lib.prh_linear_backward.argtypes = [vp, lg, vp, vp, vp, vp, vp, i, i, i, vp, sz, i, vp]
+    lib.prh_mlp_stack_workspace_bytes.restype = sz
+    lib.prh_mlp_stack_workspace_bytes.argtypes = [i, i, C.POINTER(BnLayer)]
+    lib.prh_mlp_stack_forward.restype = i
+    lib.prh_mlp_stack_forward.argtypes = [C.POINTER(BnLayer), i, i, vp, i, i, f, f, vp, vp, vp, vp,
+                                          vp, vp, vp, sz, i, vp]
+    lib.prh_mlp_stack_backward.restype = i
+    lib.prh_mlp_stack_backward.argtypes = [C.POINTER(BnLayer), i, i, vp, i, i, vp, vp, vp, vp, vp,
+                                           vp, C.POINTER(BnLayerGrad), vp, vp, sz, i, vp]
+    lib.prh_test_gemm_nt.restype = i
+    lib.prh_test_gemm_nt.argtypes = [vp, vp, vp, i, i, i, i, vp]
+    lib.prh_test_gemm_tn_workspace_bytes.restype = sz
+    lib.prh_test_gemm_tn_workspace_bytes.argtypes = [i, i, i]
+    lib.prh_test_gemm_tn.restype = i
+    lib.prh_test_gemm_tn.argtypes = [vp, vp, vp, vp, i, i, i, vp, sz, i, vp]
+    return lib
+
+
+def lib():
+    """The loaded library; raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                        "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+                _lib = _bind(C.CDLL(LIB_PATH))
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().prh_last_error().decode(errors="replace")
+        if rc == -1:
+            raise RuntimeError(f"{what}: {msg}")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")

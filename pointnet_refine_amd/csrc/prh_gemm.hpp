@@ -1,0 +1,423 @@
+// fp32 MFMA GEMM cores for the LineRefineNet shared-MLP path on gfx950 (MI355X).
+//
+// Two cores, both on v_mfma_f32_32x32x2_f32 (exact fp32 = an fmaf chain, so the
+// 1e-4 parity gate against the CPU reference holds with ~1e-6 to spare):
+//
+//   gemm_nt : C[M,N] = pro(A)[M,K] * W[N,K]^T   rows = points, K-contiguous operands.
+//             Every forward 1x1 conv / Linear and every dgrad (with W^T materialised).
+//   gemm_tn : C[Mo,Ni] = sum_p proA(A)[p,Mo] * proB(B)[p,Ni]   (wgrad, reduce over points,
+//             split over row ranges into slabs that a second kernel sums).
+//
+// What makes them the "fused shared MLP" rather than library GEMMs is what rides on the
+// operand staging (prologue) and on the accumulator tile (epilogue):
+//   prologue  BNRELU : a = relu(z*s[k] + t[k])      BatchNorm+ReLU applied while staging,
+//                                                   so post-activation tensors never exist
+//             BNBWD  : a = pa[k]*dy + pb[k]*z + pc[k]  BatchNorm backward applied on load
+//             GATE1  : a = relu(i*w1[k] + b1[k])    intensity-gate hidden layer from 1 scalar
+//   epilogue  bias, per-column batch statistics (sum, centred M2 per 64-row wave tile),
+//             gate combine F = relu(zf*s+t) * (0.5+0.5*sigmoid(acc+b)), ReLU-mask +
+//             accumulate + BN-backward statistics for dgrad.
+//
+// Layout: everything is POINT-MAJOR [rows = B*N points][channels]; a wave's global loads
+// are 16 B per lane along channels, 128 B contiguous per 8 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace prh {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { PRO_NONE = 0, PRO_BNRELU = 1, PRO_BNBWD = 2, PRO_GATE1 = 3 };
+enum { EPI_BIAS = 0, EPI_BIAS_STATS = 1, EPI_GATE = 2, EPI_DGRAD = 3 };
+
+// flags
+enum {
+  F_RELU_OUT = 1,     // EPI_BIAS: C = relu(acc+bias)
+  F_ACCUM = 2,        // EPI_DGRAD: v = acc + C_old
+  F_MASK = 4,         // EPI_DGRAD: v *= (E1*es+et > 0)
+  F_STATS = 8,        // EPI_DGRAD: write per-wave column sums of v and v*E1
+  F_STORE_GATE = 16,  // EPI_GATE: also store m = 0.5+0.5*sigmoid() to C2
+  F_E1_ROWVEC = 32,   // EPI_DGRAD: E1 is one value per row (E1[row*lde1]), not a matrix
+};
+
+struct NTParams {
+  const float* A;  long lda;     // [M,K]
+  const float* A2; long lda2;    // PRO_BNBWD: z
+  const float* W;  long ldw;     // [N,K]
+  float* C;        long ldc;     // [M,N]
+  int M, N, K;
+  const float* bias;             // [N] or null
+  const float* pa; const float* pb; const float* pc;   // prologue vectors over K
+  const float* E1; long lde1;    // epilogue operand [M,N] (zf for GATE, z for DGRAD mask)
+  const float* es; const float* et;  // epilogue per-column scale/shift
+  float* C2;       long ldc2;    // EPI_GATE second output
+  float* ws_a; float* ws_b;      // stats partials [2*row_tiles][N]
+  int flags;
+  int tiles_n;
+};
+
+constexpr int BM = 128, BN = 128, BK = 32;
+
+__device__ __forceinline__ int crow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// swizzled LDS float offset of 16-B slot `slot` (0..7) in row `row` of a [rows][32] tile.
+// ds_read_b128 lane groups hold 16 lanes with distinct row mod 16 -> conflict free.
+__device__ __forceinline__ int lds_off(int row, int slot) {
+  return row * BK + ((slot ^ ((row >> 1) & 7)) << 2);
+}
+
+template <int PRO>
+__device__ __forceinline__ float4 pro_apply(float4 a, float4 a2, float4 ka, float4 kb, float4 kc) {
+  float4 o;
+  if (PRO == PRO_NONE) {
+    o = a;
+  } else if (PRO == PRO_BNRELU) {
+    o.x = fmaxf(fmaf(a.x, ka.x, kb.x), 0.f); o.y = fmaxf(fmaf(a.y, ka.y, kb.y), 0.f);
+    o.z = fmaxf(fmaf(a.z, ka.z, kb.z), 0.f); o.w = fmaxf(fmaf(a.w, ka.w, kb.w), 0.f);
+  } else if (PRO == PRO_BNBWD) {
+    o.x = fmaf(ka.x, a.x, fmaf(kb.x, a2.x, kc.x)); o.y = fmaf(ka.y, a.y, fmaf(kb.y, a2.y, kc.y));
+    o.z = fmaf(ka.z, a.z, fmaf(kb.z, a2.z, kc.z)); o.w = fmaf(ka.w, a.w, fmaf(kb.w, a2.w, kc.w));
+  } else {  // PRO_GATE1: a.x holds the row's intensity
+    o.x = fmaxf(fmaf(a.x, ka.x, kb.x), 0.f); o.y = fmaxf(fmaf(a.x, ka.y, kb.y), 0.f);
+    o.z = fmaxf(fmaf(a.x, ka.z, kb.z), 0.f); o.w = fmaxf(fmaf(a.x, ka.w, kb.w), 0.f);
+  }
+  return o;
+}
+
+__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+template <int PRO, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NTParams p) {
+  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * BK];
+  float* As = smem;
+  float* Ws = smem + BM * BK;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int tile_n = blockIdx.x % p.tiles_n, tile_m = blockIdx.x / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int sr = tid >> 3;         // staging row 0..31 (+32*j)
+  const int sk = (tid & 7) * 4;    // staging k offset inside the k-tile
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[4], ra2[4], rw[4];
+  const int nk = (p.K + BK - 1) / BK;
+
+  auto load_tile = [&](int kt) {
+    const int k = kt * BK + sk;
+    const bool kok = k < p.K;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = m0 + sr + 32 * j;
+      const bool ok = kok && row < p.M;
+      if (PRO == PRO_GATE1) {
+        ra[j] = zero4();
+        if (ok) ra[j].x = p.A[(size_t)row * p.lda];
+      } else {
+        ra[j] = ok ? ldg4(p.A + (size_t)row * p.lda + k) : zero4();
+        if (PRO == PRO_BNBWD) ra2[j] = ok ? ldg4(p.A2 + (size_t)row * p.lda2 + k) : zero4();
+      }
+      const int n = n0 + sr + 32 * j;
+      rw[j] = (kok && n < p.N) ? ldg4(p.W + (size_t)n * p.ldw + k) : zero4();
+    }
+  };
+  auto store_tile = [&](int kt) {
+    const int k = kt * BK + sk;
+    const bool kok = k < p.K;
+    float4 ka = zero4(), kb = zero4(), kc = zero4();
+    if (PRO != PRO_NONE && kok) {
+      ka = ldg4(p.pa + k);
+      kb = ldg4(p.pb + k);
+      if (PRO == PRO_BNBWD) kc = ldg4(p.pc + k);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = sr + 32 * j;
+      const bool ok = kok && (m0 + r) < p.M;
+      float4 v = ok ? pro_apply<PRO>(ra[j], ra2[j], ka, kb, kc) : zero4();
+      *reinterpret_cast<float4*>(As + lds_off(r, sk >> 2)) = v;
+      *reinterpret_cast<float4*>(Ws + lds_off(r, sk >> 2)) = rw[j];
+    }
+  };
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 a4[2], b4[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        a4[t] = *reinterpret_cast<const float4*>(As + lds_off(wm + t * 32 + l31, g * 2 + half));
+        b4[t] = *reinterpret_cast<const float4*>(Ws + lds_off(wn + t * 32 + l31, g * 2 + half));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].x, b4[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].y, b4[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].z, b4[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].w, b4[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+      store_tile(kt + 1);
+      __syncthreads();
+    }
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  const int rbase = m0 + wm;
+  const int rb2 = tile_m * 2 + (wave >> 1);
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int col = n0 + wn + nt * 32 + l31;
+    const bool cok = col < p.N;
+    const float bias = (p.bias != nullptr && cok) ? p.bias[col] : 0.f;
+
+    if (EPI == EPI_BIAS || EPI == EPI_BIAS_STATS) {
+      float s = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + mt * 32 + crow(r, half);
+          float v = acc[mt][nt][r] + bias;
+          if ((p.flags & F_RELU_OUT) != 0) v = fmaxf(v, 0.f);
+          acc[mt][nt][r] = v;
+          if (row < p.M && cok) {
+            p.C[(size_t)row * p.ldc + col] = v;
+            s += v;
+          }
+        }
+      if (EPI == EPI_BIAS_STATS) {
+        s += __shfl_xor(s, 32);
+        int nrows = p.M - rbase;
+        nrows = nrows < 0 ? 0 : (nrows > 64 ? 64 : nrows);
+        const float mean = nrows > 0 ? s / (float)nrows : 0.f;
+        float m2 = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = rbase + mt * 32 + crow(r, half);
+            const float d = acc[mt][nt][r] - mean;
+            if (row < p.M) m2 = fmaf(d, d, m2);
+          }
+        m2 += __shfl_xor(m2, 32);
+        if (half == 0 && cok) {
+          p.ws_a[(size_t)rb2 * p.N + col] = s;
+          p.ws_b[(size_t)rb2 * p.N + col] = m2;
+        }
+      }
+    } else if (EPI == EPI_GATE) {
+      const float es = cok ? p.es[col] : 0.f, et = cok ? p.et[col] : 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + mt * 32 + crow(r, half);
+          if (row < p.M && cok) {
+            const float g = acc[mt][nt][r] + bias;
+            const float m = 0.5f + 0.5f / (1.f + __expf(-g));
+            const float zf = p.E1[(size_t)row * p.lde1 + col];
+            const float rl = fmaxf(fmaf(zf, es, et), 0.f);
+            p.C[(size_t)row * p.ldc + col] = rl * m;
+            if ((p.flags & F_STORE_GATE) != 0) p.C2[(size_t)row * p.ldc2 + col] = m;
+          }
+        }
+    } else {  // EPI_DGRAD
+      const bool mask = (p.flags & F_MASK) != 0, accum = (p.flags & F_ACCUM) != 0;
+      const bool need_z = mask || (p.flags & F_STATS) != 0;
+      const float es = (mask && cok) ? p.es[col] : 0.f, et = (mask && cok) ? p.et[col] : 0.f;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + mt * 32 + crow(r, half);
+          if (row < p.M && cok) {
+            float v = acc[mt][nt][r] + bias;
+            if (accum) v += p.C[(size_t)row * p.ldc + col];
+            float z = 0.f;
+            if (need_z) z = p.E1[(size_t)row * p.lde1 + ((p.flags & F_E1_ROWVEC) ? 0 : col)];
+            if (mask && !(fmaf(z, es, et) > 0.f)) v = 0.f;
+            p.C[(size_t)row * p.ldc + col] = v;
+            s1 += v;
+            s2 = fmaf(v, z, s2);
+          }
+        }
+      if ((p.flags & F_STATS) != 0) {
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (half == 0 && cok) {
+          p.ws_a[(size_t)rb2 * p.N + col] = s1;
+          p.ws_b[(size_t)rb2 * p.N + col] = s2;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// wgrad core: C[Mo,Ni] (+)= sum over rows p in this split of proA(A)[p,Mo] * proB(B)[p,Ni]
+// ---------------------------------------------------------------------------------------
+struct TNParams {
+  const float* A;  long lda;     // [P,Mo]  (dy)
+  const float* A2; long lda2;    // PRO_BNBWD: z
+  const float* B;  long ldb;     // [P,Ni]  (z_prev / x / intensity column for GATE1)
+  int P, Mo, Ni;
+  const float* pa; const float* pb; const float* pc;   // A prologue over Mo
+  const float* qa; const float* qb;                    // B prologue over Ni
+  float* slab;        // [splits][Mo][Ni]
+  float* colsum;      // [splits][Mo] column sums of proA(A), or null
+  int splits; int rows_per_split;
+  int tiles_m, tiles_n;
+};
+
+template <int PROA, int PROB>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TNParams p) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * BK * 128];
+  float* As = smem;              // [BK][128]  (k = point rows, m contiguous)
+  float* Bs = smem + BK * 128;   // [BK][128]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  int b = blockIdx.x;
+  const int tile_n = b % p.tiles_n; b /= p.tiles_n;
+  const int tile_m = b % p.tiles_m; b /= p.tiles_m;
+  const int split = b;
+  const int m0 = tile_m * 128, n0 = tile_n * 128;
+  const int p_begin = split * p.rows_per_split;
+  int p_end = p_begin + p.rows_per_split;
+  if (p_end > p.P) p_end = p.P;
+
+  const int sc = (tid & 31) * 4;   // staging column (float4)
+  const int sr = tid >> 5;         // staging row 0..7 (+8*j)
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const bool aok = (m0 + sc) < p.Mo, bok = (n0 + sc) < p.Ni;
+  float4 ka = zero4(), kb = zero4(), kc = zero4(), qa = zero4(), qb = zero4();
+  if (PROA != PRO_NONE && aok) {
+    ka = ldg4(p.pa + m0 + sc);
+    kb = ldg4(p.pb + m0 + sc);
+    if (PROA == PRO_BNBWD) kc = ldg4(p.pc + m0 + sc);
+  }
+  if (PROB != PRO_NONE && bok) {
+    qa = ldg4(p.qa + n0 + sc);
+    qb = ldg4(p.qb + n0 + sc);
+  }
+  const bool do_colsum = (p.colsum != nullptr) && tile_n == 0;
+  float4 csum = zero4();
+
+  float4 ra[4], ra2[4], rb[4];
+  const int nk = (p_end - p_begin + BK - 1) / BK;
+
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = p_begin + kt * BK + sr + 8 * j;
+      const bool rok = row < p_end;
+      ra[j] = (rok && aok) ? ldg4(p.A + (size_t)row * p.lda + m0 + sc) : zero4();
+      if (PROA == PRO_BNBWD) ra2[j] = (rok && aok) ? ldg4(p.A2 + (size_t)row * p.lda2 + m0 + sc) : zero4();
+      if (PROB == PRO_GATE1) {
+        rb[j] = zero4();
+        if (rok && bok) rb[j].x = p.B[(size_t)row * p.ldb];
+      } else {
+        rb[j] = (rok && bok) ? ldg4(p.B + (size_t)row * p.ldb + n0 + sc) : zero4();
+      }
+    }
+  };
+  auto store_tile = [&](int kt) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = sr + 8 * j;
+      const bool rok = (p_begin + kt * BK + r) < p_end;
+      float4 va = (rok && aok) ? pro_apply<PROA>(ra[j], ra2[j], ka, kb, kc) : zero4();
+      float4 vb = (rok && bok) ? pro_apply<PROB>(rb[j], rb[j], qa, qb, qb) : zero4();
+      csum.x += va.x; csum.y += va.y; csum.z += va.z; csum.w += va.w;
+      *reinterpret_cast<float4*>(As + r * 128 + sc) = va;
+      *reinterpret_cast<float4*>(Bs + r * 128 + sc) = vb;
+    }
+  };
+
+  if (nk > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float a[2], bb[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        a[t] = As[(kk * 2 + half) * 128 + wm + t * 32 + l31];
+        bb[t] = Bs[(kk * 2 + half) * 128 + wn + t * 32 + l31];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+      store_tile(kt + 1);
+      __syncthreads();
+    }
+  }
+
+  float* out = p.slab + (size_t)split * p.Mo * p.Ni;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int col = n0 + wn + nt * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm + mt * 32 + crow(r, half);
+        if (row < p.Mo && col < p.Ni) out[(size_t)row * p.Ni + col] = acc[mt][nt][r];
+      }
+    }
+
+  if (do_colsum) {
+    __syncthreads();
+    float* red = smem;   // [8][128]
+    *reinterpret_cast<float4*>(red + sr * 128 + sc) = csum;
+    __syncthreads();
+    if (tid < 128) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) s += red[r * 128 + tid];
+      if (m0 + tid < p.Mo) p.colsum[(size_t)split * p.Mo + m0 + tid] = s;
+    }
+  }
+}
+
+}  // namespace prh

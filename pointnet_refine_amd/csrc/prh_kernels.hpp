@@ -1,0 +1,359 @@
+// Small kernels around the GEMM cores: BatchNorm statistics finalisation (forward and
+// backward), eval-mode BN coefficients, dual pooling, the gate/BN-ReLU combine backward,
+// weight transposes, slab reductions, column padding.  All fp32 storage; cross-tile
+// reductions are combined in fp64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace prh {
+
+// ---------------------------------------------------------------------------------------
+// BatchNorm forward statistics.  Input: per-64-row-wave-tile partials written by
+// gemm_nt<.., EPI_BIAS_STATS>: ws_sum[i][c] = sum of the tile's rows, ws_m2[i][c] = sum of
+// squared deviations from the TILE mean (Chan et al. pairwise form, so no E[x^2]-E[x]^2
+// cancellation).  Output: mean, rstd, scale = gamma*rstd, shift = beta - mean*scale, and
+// the running-stat update of nn.BatchNorm1d (momentum, UNBIASED variance).
+// grid = ceil(N/32), block = 1024 = 32 columns x 32 row groups.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void bn_fwd_finalize_kernel(
+    const float* __restrict__ ws_sum, const float* __restrict__ ws_m2, int R2, int P, int N,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
+    float* running_var, int64_t* nbt, float momentum, float eps, float* mean_out,
+    float* rstd_out, float* scale_out, float* shift_out) {
+  __shared__ double red[32][33];
+  __shared__ double mu_s[32];
+  const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + c;
+  const bool ok = col < N;
+  double s = 0.0;
+  if (ok)
+    for (int i = g; i < R2; i += 32) s += (double)ws_sum[(size_t)i * N + col];
+  red[g][c] = s;
+  __syncthreads();
+  if (g == 0) {
+    double t = 0.0;
+    for (int j = 0; j < 32; ++j) t += red[j][c];
+    mu_s[c] = t / (double)P;
+  }
+  __syncthreads();
+  const double mu = mu_s[c];
+  double m2 = 0.0;
+  if (ok)
+    for (int i = g; i < R2; i += 32) {
+      int n = P - i * 64;
+      n = n > 64 ? 64 : n;
+      if (n <= 0) continue;
+      const double mi = (double)ws_sum[(size_t)i * N + col] / (double)n;
+      const double d = mi - mu;
+      m2 += (double)ws_m2[(size_t)i * N + col] + d * d * (double)n;
+    }
+  __syncthreads();
+  red[g][c] = m2;
+  __syncthreads();
+  if (g == 0 && ok) {
+    double t = 0.0;
+    for (int j = 0; j < 32; ++j) t += red[j][c];
+    const double var = t / (double)P;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const float sc = (float)((double)gamma[col] * rstd);
+    mean_out[col] = (float)mu;
+    rstd_out[col] = (float)rstd;
+    scale_out[col] = sc;
+    shift_out[col] = (float)((double)beta[col] - mu * (double)gamma[col] * rstd);
+    if (running_mean != nullptr) {
+      const double unb = P > 1 ? t / (double)(P - 1) : var;
+      running_mean[col] = (float)((1.0 - momentum) * (double)running_mean[col] + momentum * mu);
+      running_var[col] = (float)((1.0 - momentum) * (double)running_var[col] + momentum * unb);
+    }
+  }
+  if (nbt != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
+}
+
+// eval-mode coefficients from running statistics
+__global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm,
+                                      const float* rv, float eps, int N, float* mean_out,
+                                      float* rstd_out, float* scale_out, float* shift_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  const float rstd = 1.0f / sqrtf(rv[c] + eps);
+  const float sc = gamma[c] * rstd;
+  mean_out[c] = rm[c];
+  rstd_out[c] = rstd;
+  scale_out[c] = sc;
+  shift_out[c] = beta[c] - rm[c] * sc;
+}
+
+// ---------------------------------------------------------------------------------------
+// BatchNorm backward statistics.  Partials: ws_a[i][c] = sum dy, ws_b[i][c] = sum dy*z over
+// a 64-row tile (dy already ReLU-masked).  Produces
+//   dgamma = (Sdyz - mean*Sdy)*rstd, dbeta = Sdy
+//   coefficients of dz = ca*dy + cb*z + cc  (train: full BN backward; eval: ca=scale, 0, 0)
+//   db (bias of the conv ahead of the BN) = sum dz = ca*Sdy + cb*P*mean + cc*P
+// grid = ceil(N/32), block 1024.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(
+    const float* __restrict__ ws_a, const float* __restrict__ ws_b, int R2, int P, int N,
+    const float* __restrict__ gamma, const float* __restrict__ mean,
+    const float* __restrict__ rstd, int training, float* ca, float* cb, float* cc,
+    float* dgamma, float* dbeta, float* dbias) {
+  __shared__ double red[2][32][33];
+  const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + c;
+  const bool ok = col < N;
+  double s1 = 0.0, s2 = 0.0;
+  if (ok)
+    for (int i = g; i < R2; i += 32) {
+      s1 += (double)ws_a[(size_t)i * N + col];
+      s2 += (double)ws_b[(size_t)i * N + col];
+    }
+  red[0][g][c] = s1;
+  red[1][g][c] = s2;
+  __syncthreads();
+  if (g == 0 && ok) {
+    double Sdy = 0.0, Sdyz = 0.0;
+    for (int j = 0; j < 32; ++j) {
+      Sdy += red[0][j][c];
+      Sdyz += red[1][j][c];
+    }
+    const double mu = mean[col], rs = rstd[col], gm = gamma[col];
+    const double dg = (Sdyz - mu * Sdy) * rs;
+    if (dgamma != nullptr) dgamma[col] = (float)dg;
+    if (dbeta != nullptr) dbeta[col] = (float)Sdy;
+    double a = gm * rs, b = 0.0, cst = 0.0;
+    if (training) {
+      const double m1 = Sdy / (double)P, m2 = dg / (double)P;
+      b = -a * m2 * rs;
+      cst = a * (m2 * mu * rs - m1);
+    }
+    ca[col] = (float)a;
+    cb[col] = (float)b;
+    cc[col] = (float)cst;
+    if (dbias != nullptr) dbias[col] = (float)(a * Sdy + b * (double)P * mu + cst * (double)P);
+  }
+}
+
+// plain reduction of two partial arrays over tiles: out_a[c] = sum_i ws_a[i][c] etc.
+__global__ __launch_bounds__(1024) void partials_reduce_kernel(
+    const float* __restrict__ ws_a, const float* __restrict__ ws_b, int R2, int N, float* out_a,
+    float* out_b) {
+  __shared__ double red[2][32][33];
+  const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + c;
+  const bool ok = col < N;
+  double s1 = 0.0, s2 = 0.0;
+  if (ok)
+    for (int i = g; i < R2; i += 32) {
+      s1 += (double)ws_a[(size_t)i * N + col];
+      if (ws_b != nullptr) s2 += (double)ws_b[(size_t)i * N + col];
+    }
+  red[0][g][c] = s1;
+  red[1][g][c] = s2;
+  __syncthreads();
+  if (g == 0 && ok) {
+    double a = 0.0, b = 0.0;
+    for (int j = 0; j < 32; ++j) {
+      a += red[0][j][c];
+      b += red[1][j][c];
+    }
+    if (out_a != nullptr) out_a[col] = (float)a;
+    if (out_b != nullptr) out_b[col] = (float)b;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Dual pooling over the N points of each segment, src/model.py:58-60.
+// grid = (ceil(C/64), B), block 256 = 64 columns x 4 point groups; coalesced 256-B rows.
+// Ties go to the FIRST point (torch.max semantics).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ F, int N, int C,
+                                                   float* gfeat, int32_t* argmax) {
+  __shared__ float smax[4][64];
+  __shared__ int sidx[4][64];
+  __shared__ float ssum[4][64];
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + c, b = blockIdx.y;
+  float mx = -INFINITY, sum = 0.f;
+  int ix = 0;
+  if (col < C) {
+    const float* base = F + (size_t)b * N * C + col;
+    for (int n = g; n < N; n += 4) {
+      const float v = base[(size_t)n * C];
+      sum += v;
+      if (v > mx) { mx = v; ix = n; }
+    }
+  }
+  smax[g][c] = mx; sidx[g][c] = ix; ssum[g][c] = sum;
+  __syncthreads();
+  if (g == 0 && col < C) {
+    for (int j = 1; j < 4; ++j) {
+      const float v = smax[j][c];
+      const int i2 = sidx[j][c];
+      if (v > mx || (v == mx && i2 < ix)) { mx = v; ix = i2; }
+      sum += ssum[j][c];
+    }
+    gfeat[(size_t)b * 2 * C + col] = mx;
+    gfeat[(size_t)b * 2 * C + C + col] = sum / (float)N;
+    if (argmax != nullptr) argmax[(size_t)b * C + col] = ix;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Backward of  F = relu(zf*s+t) * m,  gfeat = [max_n F | mean_n F]   (src/model.py:51-60)
+//   dF_total = dF (may be null) + d_mean/N + [n == argmax] * d_max
+//   dy  = dF_total * m * [relu>0]           -> written to dy_out (may alias dF)
+//   dG  = dF_total * r * 0.5*sig*(1-sig), sig = 2m-1   -> written over `gate` in place
+// plus the BN-backward partials (sum dy, sum dy*zf) per 64-row tile.
+// grid = (ceil(P/64), ceil(C/64)), block 256: thread = (col, 16-row group)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void combine_bwd_kernel(
+    const float* dF, const float* __restrict__ d_gfeat, const int32_t* __restrict__ argmax,
+    const float* __restrict__ zf, float* gate, const float* __restrict__ s,
+    const float* __restrict__ t, int P, int N, int C, float* dy_out, float* ws_a, float* ws_b) {
+  __shared__ float r1[4][64], r2[4][64];
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int col = blockIdx.y * 64 + c;
+  const int row0 = blockIdx.x * 64 + g * 16;
+  float s1 = 0.f, s2 = 0.f;
+  if (col < C) {
+    const float sc = s[col], sh = t[col];
+    for (int i = 0; i < 16; ++i) {
+      const int row = row0 + i;
+      if (row >= P) break;
+      const size_t off = (size_t)row * C + col;
+      float d = dF != nullptr ? dF[off] : 0.f;
+      if (d_gfeat != nullptr) {
+        const int b = row / N, n = row - b * N;
+        d += d_gfeat[(size_t)b * 2 * C + C + col] / (float)N;
+        if (argmax[(size_t)b * C + col] == n) d += d_gfeat[(size_t)b * 2 * C + col];
+      }
+      const float z = zf[off], m = gate[off];
+      const float pre = fmaf(z, sc, sh);
+      const float r = fmaxf(pre, 0.f);
+      const float sig = 2.f * m - 1.f;
+      const float dy = pre > 0.f ? d * m : 0.f;
+      gate[off] = d * r * 0.5f * sig * (1.f - sig);
+      dy_out[off] = dy;
+      s1 += dy;
+      s2 = fmaf(dy, z, s2);
+    }
+  }
+  r1[g][c] = s1; r2[g][c] = s2;
+  __syncthreads();
+  if (g == 0 && col < C) {
+    for (int j = 1; j < 4; ++j) { s1 += r1[j][c]; s2 += r2[j][c]; }
+    ws_a[(size_t)blockIdx.x * C + col] = s1;
+    ws_b[(size_t)blockIdx.x * C + col] = s2;
+  }
+}
+
+// Generic BN(+ReLU) apply  y = [relu](z*s+t)  and its backward-side twin
+//   dy = dh * [z*s+t > 0]  with per-64-row partial sums (sum dy, sum dy*z).
+// Used for the last layer of an MLP stack (point_mlp) where no GEMM consumes z.
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ z, long ldz,
+                                                       const float* __restrict__ s,
+                                                       const float* __restrict__ t, int P, int C,
+                                                       int relu, float* y, long ldy) {
+  const int col = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int row0 = blockIdx.x * 64 + (threadIdx.x >> 6) * 16;
+  if (col >= C) return;
+  const float sc = s[col], sh = t[col];
+  for (int i = 0; i < 16; ++i) {
+    const int row = row0 + i;
+    if (row >= P) break;
+    float v = fmaf(z[(size_t)row * ldz + col], sc, sh);
+    if (relu) v = fmaxf(v, 0.f);
+    y[(size_t)row * ldy + col] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_dy_stats_kernel(
+    const float* __restrict__ dh, long lddh, const float* __restrict__ z, long ldz,
+    const float* __restrict__ s, const float* __restrict__ t, int P, int C, int relu,
+    float* dy, long lddy, float* ws_a, float* ws_b) {
+  __shared__ float r1[4][64], r2[4][64];
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int col = blockIdx.y * 64 + c;
+  const int row0 = blockIdx.x * 64 + g * 16;
+  float s1 = 0.f, s2 = 0.f;
+  if (col < C) {
+    const float sc = s[col], sh = t[col];
+    for (int i = 0; i < 16; ++i) {
+      const int row = row0 + i;
+      if (row >= P) break;
+      const float zz = z[(size_t)row * ldz + col];
+      float d = dh[(size_t)row * lddh + col];
+      if (relu && !(fmaf(zz, sc, sh) > 0.f)) d = 0.f;
+      dy[(size_t)row * lddy + col] = d;
+      s1 += d;
+      s2 = fmaf(d, zz, s2);
+    }
+  }
+  r1[g][c] = s1; r2[g][c] = s2;
+  __syncthreads();
+  if (g == 0 && col < C) {
+    for (int j = 1; j < 4; ++j) { s1 += r1[j][c]; s2 += r2[j][c]; }
+    ws_a[(size_t)blockIdx.x * C + col] = s1;
+    ws_b[(size_t)blockIdx.x * C + col] = s2;
+  }
+}
+
+// out[c][r] = in[r][c], in is [R][C] (weights only: a few MB per step)
+__global__ void transpose_kernel(const float* __restrict__ in, int R, int C, long ldin,
+                                 float* out, long ldout) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    const int r = r0 + j, c = c0 + tx;
+    tile[j][tx] = (r < R && c < C) ? in[(size_t)r * ldin + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j, r = r0 + tx;
+    if (c < C && r < R) out[(size_t)c * ldout + r] = tile[tx][j];
+  }
+}
+
+// out[i] = sum_s slab[s][i]  (out may have a leading dimension: [rows][cols] -> ld)
+__global__ void slab_reduce_kernel(const float* __restrict__ slab, int S, int rows, int cols,
+                                   float* out, long ldout) {
+  const size_t len = (size_t)rows * cols;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= len) return;
+  double acc = 0.0;
+  for (int s = 0; s < S; ++s) acc += (double)slab[(size_t)s * len + i];
+  const size_t r = i / cols, c = i - r * cols;
+  out[r * ldout + c] = (float)acc;
+}
+
+// dst[r][0..cd) = src[r][0..cs) zero-padded (cd >= cs); or truncation when cd < cs
+__global__ void copy_cols_kernel(const float* __restrict__ src, long lds_, int cs, float* dst,
+                                 long ldd, int cd, size_t rows) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * (size_t)cd) return;
+  const size_t r = i / cd;
+  const int c = (int)(i - r * cd);
+  dst[r * ldd + c] = c < cs ? src[r * lds_ + c] : 0.f;
+}
+
+// d_ctx[p][3] += sum_c dU[p][c]*w1[c]   (gate hidden layer back to the intensity channel)
+__global__ __launch_bounds__(256) void gate1_dctx_kernel(const float* __restrict__ dU, int P,
+                                                         int H, const float* __restrict__ w1,
+                                                         float* d_ctx, long ldc) {
+  const int lane = threadIdx.x & 63;
+  const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (size_t)P) return;
+  float s = 0.f;
+  for (int c = lane; c < H; c += 64) s = fmaf(dU[row * H + c], w1[c], s);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) d_ctx[row * ldc + 3] += s;
+}
+
+__global__ void fill_kernel(float* p, size_t n, float v) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+}  // namespace prh

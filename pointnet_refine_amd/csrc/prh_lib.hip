@@ -1,0 +1,724 @@
+// C-ABI entry points of libpointnet_refine_hip.so (see include/pointnet_refine_hip.h).
+// Host-side orchestration only: argument checks, workspace carving, kernel launches on the
+// caller's stream.  No allocation, no synchronisation, no state kept between calls, so a
+// whole forward or backward can be captured into a hipGraph by the caller.
+#include "../../include/pointnet_refine_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "prh_gemm.hpp"
+#include "prh_kernels.hpp"
+
+using namespace prh;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                  \
+  do {                                                                                 \
+    hipError_t e_ = (expr);                                                            \
+    if (e_ != hipSuccess)                                                              \
+      return fail(PRH_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
+                  __FILE__, __LINE__);                                                 \
+  } while (0)
+
+#define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// bump allocator over the caller's workspace (256-B aligned carves).  With base == nullptr
+// it only measures: the *_workspace_bytes queries run the SAME carve functions as the entry
+// points, so the two can never disagree.
+struct Arena {
+  char* base; size_t size; size_t off = 0; bool ok = true;
+  Arena(void* b, size_t s) : base((char*)b), size(s) {}
+  Arena() : base(nullptr), size((size_t)-1) {}
+  float* f(size_t n) {
+    off = align_up(off, 256);
+    const size_t bytes = n * sizeof(float);
+    if (base != nullptr && off + bytes > size) { ok = false; return nullptr; }
+    float* p = base ? (float*)(base + off) : nullptr;
+    off += bytes;
+    return p;
+  }
+};
+
+inline int stat_tiles(int P) { return 2 * cdiv(P, BM); }   // 64-row partial tiles
+
+// ------------------------------------------------------------------ launch helpers
+template <int PRO, int EPI>
+int launch_nt(NTParams p, hipStream_t st) {
+  if (p.M <= 0 || p.N <= 0) return PRH_OK;
+  if ((p.K & 3) || (PRO != PRO_GATE1 && (p.lda & 3)) || (p.ldw & 3) ||
+      (PRO == PRO_BNBWD && (p.lda2 & 3)))
+    return fail(PRH_ERR_ARG, "gemm_nt: K/lda/ldw must be multiples of 4 (K=%d lda=%ld ldw=%ld)",
+                p.K, p.lda, p.ldw);
+  p.tiles_n = cdiv(p.N, BN);
+  const long tiles = (long)p.tiles_n * cdiv(p.M, BM);
+  hipLaunchKernelGGL((gemm_nt_kernel<PRO, EPI>), dim3((unsigned)tiles), dim3(256), 0, st, p);
+  LAUNCH_CHECK();
+  return PRH_OK;
+}
+
+struct TNPlan { int tiles_m, tiles_n, splits, rows_per_split; };
+inline TNPlan tn_plan(int P, int Mo, int Ni) {
+  TNPlan pl;
+  pl.tiles_m = cdiv(Mo, 128);
+  pl.tiles_n = cdiv(Ni, 128);
+  const int tiles = pl.tiles_m * pl.tiles_n;
+  int s = cdiv(1024, tiles);
+  const int smax = cdiv(P, 512) < 1 ? 1 : cdiv(P, 512);
+  if (s > smax) s = smax;
+  if (s < 1) s = 1;
+  int rps = cdiv(P, s);
+  rps = cdiv(rps, BK) * BK;
+  if (rps < BK) rps = BK;
+  pl.splits = cdiv(P, rps) < 1 ? 1 : cdiv(P, rps);
+  pl.rows_per_split = rps;
+  return pl;
+}
+inline size_t tn_slab_floats(int P, int Mo, int Ni) {
+  TNPlan pl = tn_plan(P, Mo, Ni);
+  return (size_t)pl.splits * Mo * Ni;
+}
+inline size_t tn_colsum_floats(int P, int Mo, int Ni) {
+  TNPlan pl = tn_plan(P, Mo, Ni);
+  return (size_t)pl.splits * Mo;
+}
+
+// C[Mo,Ni] (ld ldc) = proA(A)^T proB(B); colsum_out[Mo] = column sums of proA(A) (optional)
+template <int PROA, int PROB>
+int launch_tn(TNParams p, float* slab, float* colsum_slab, float* C, long ldc, float* colsum_out,
+              hipStream_t st) {
+  if (p.Mo <= 0 || p.Ni <= 0) return PRH_OK;
+  if ((p.Mo & 3) || (p.Ni & 3) || (p.lda & 3) || (PROB != PRO_GATE1 && (p.ldb & 3)))
+    return fail(PRH_ERR_ARG, "gemm_tn: Mo/Ni/lda/ldb must be multiples of 4 (Mo=%d Ni=%d)", p.Mo,
+                p.Ni);
+  TNPlan pl = tn_plan(p.P, p.Mo, p.Ni);
+  p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n; p.splits = pl.splits;
+  p.rows_per_split = pl.rows_per_split;
+  p.slab = slab;
+  p.colsum = colsum_out != nullptr ? colsum_slab : nullptr;
+  const long blocks = (long)pl.tiles_m * pl.tiles_n * pl.splits;
+  hipLaunchKernelGGL((gemm_tn_kernel<PROA, PROB>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+  LAUNCH_CHECK();
+  if (C != nullptr) {
+    const size_t len = (size_t)p.Mo * p.Ni;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv((long)len, 256)), dim3(256), 0, st, slab,
+                       pl.splits, p.Mo, p.Ni, C, ldc);
+    LAUNCH_CHECK();
+  }
+  if (colsum_out != nullptr) {
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(p.Mo, 256)), dim3(256), 0, st, colsum_slab,
+                       pl.splits, 1, p.Mo, colsum_out, (long)p.Mo);
+    LAUNCH_CHECK();
+  }
+  return PRH_OK;
+}
+
+int transpose(const float* in, int R, int C, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(256), 0, st, in, R, C,
+                     (long)C, out, (long)R);
+  LAUNCH_CHECK();
+  return PRH_OK;
+}
+
+int copy_cols(const float* src, long lds_, int cs, float* dst, long ldd, int cd, size_t rows,
+              hipStream_t st) {
+  const size_t n = rows * (size_t)cd;
+  if (n == 0) return PRH_OK;
+  hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src,
+                     lds_, cs, dst, ldd, cd, rows);
+  LAUNCH_CHECK();
+  return PRH_OK;
+}
+
+#define TRY(x)                \
+  do {                        \
+    int rc_ = (x);            \
+    if (rc_ != PRH_OK) return rc_; \
+  } while (0)
+
+// ------------------------------------------------------------------ shared-MLP stack
+// Layers l = 0..L-1:  z_l = h_{l-1} W_l^T + b_l ;  h_l = relu(BN_l(z_l)), h_{-1} = x.
+// z_l live side by side in z_cat [P, sum cout] (column offset off_l); BN coefficient vectors
+// are concatenated the same way.  h_l is never stored: consumers re-apply BN+ReLU on load.
+struct StackDims {
+  int L; int off[PRH_MAX_LAYERS + 1]; int cin0, cin0p;
+};
+StackDims stack_dims(const prh_bn_layer* ly, int L) {
+  StackDims d;
+  d.L = L;
+  d.off[0] = 0;
+  for (int l = 0; l < L; ++l) d.off[l + 1] = d.off[l] + ly[l].cout;
+  d.cin0 = ly[0].cin;
+  d.cin0p = (int)align_up((size_t)d.cin0, 4);
+  return d;
+}
+
+int check_stack(const prh_bn_layer* ly, int L) {
+  if (L < 1 || L > PRH_MAX_LAYERS) return fail(PRH_ERR_ARG, "n_layers %d out of range", L);
+  for (int l = 0; l < L; ++l) {
+    if (ly[l].cout % 4) return fail(PRH_ERR_ARG, "layer %d: cout=%d must be a multiple of 4", l, ly[l].cout);
+    if (l > 0 && ly[l].cin != ly[l - 1].cout)
+      return fail(PRH_ERR_ARG, "layer %d: cin=%d != previous cout=%d", l, ly[l].cin, ly[l - 1].cout);
+    if (!ly[l].w || !ly[l].b || !ly[l].gamma || !ly[l].beta || !ly[l].running_mean || !ly[l].running_var)
+      return fail(PRH_ERR_ARG, "layer %d: null parameter pointer", l);
+  }
+  return PRH_OK;
+}
+
+// workspace carve shared by forward/backward of a stack
+struct StackWS {
+  float* xpad = nullptr;    // [P, cin0p] when cin0 % 4 != 0
+  float* w0pad = nullptr;   // [cout0, cin0p]
+  float* ws_a = nullptr;    // stats partials [stat_tiles][maxc]
+  float* ws_b = nullptr;
+};
+bool stack_ws_carve(Arena& a, StackWS& w, int P, const prh_bn_layer* ly, int L, int maxc) {
+  StackDims d = stack_dims(ly, L);
+  if (d.cin0p != d.cin0) { w.xpad = a.f((size_t)P * d.cin0p); w.w0pad = a.f((size_t)ly[0].cout * d.cin0p); }
+  w.ws_a = a.f((size_t)stat_tiles(P) * maxc);
+  w.ws_b = a.f((size_t)stat_tiles(P) * maxc);
+  return a.ok;
+}
+
+int bn_coeffs(const prh_bn_layer& ly, int P, int training, float momentum, float eps,
+              const float* ws_a, const float* ws_b, float* mean, float* rstd, float* scale,
+              float* shift, hipStream_t st) {
+  if (training) {
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(cdiv(ly.cout, 32)), dim3(1024), 0, st, ws_a,
+                       ws_b, stat_tiles(P), P, ly.cout, ly.gamma, ly.beta, ly.running_mean,
+                       ly.running_var, ly.num_batches_tracked, momentum, eps, mean, rstd, scale,
+                       shift);
+  } else {
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(cdiv(ly.cout, 256)), dim3(256), 0, st, ly.gamma,
+                       ly.beta, ly.running_mean, ly.running_var, eps, ly.cout, mean, rstd, scale,
+                       shift);
+  }
+  LAUNCH_CHECK();
+  return PRH_OK;
+}
+
+// forward of the stack into z_cat (ld = ldz); coefficient vectors indexed by off_l
+int stack_forward(const prh_bn_layer* ly, int L, const float* x, int P, int training,
+                  float momentum, float eps, float* z_cat, long ldz, float* scale, float* shift,
+                  float* mean, float* rstd, StackWS& w, hipStream_t st) {
+  StackDims d = stack_dims(ly, L);
+  const float* x0 = x; long ldx = d.cin0; const float* w0 = ly[0].w; int k0 = d.cin0;
+  if (d.cin0p != d.cin0) {
+    TRY(copy_cols(x, d.cin0, d.cin0, w.xpad, d.cin0p, d.cin0p, (size_t)P, st));
+    TRY(copy_cols(ly[0].w, d.cin0, d.cin0, w.w0pad, d.cin0p, d.cin0p, (size_t)ly[0].cout, st));
+    x0 = w.xpad; ldx = d.cin0p; w0 = w.w0pad; k0 = d.cin0p;
+  }
+  for (int l = 0; l < L; ++l) {
+    NTParams p; memset(&p, 0, sizeof(p));
+    p.M = P; p.N = ly[l].cout; p.bias = ly[l].b;
+    p.C = z_cat + d.off[l]; p.ldc = ldz;
+    p.ws_a = w.ws_a; p.ws_b = w.ws_b;
+    if (l == 0) {
+      p.A = x0; p.lda = ldx; p.W = w0; p.ldw = k0; p.K = k0;
+      if (training) TRY((launch_nt<PRO_NONE, EPI_BIAS_STATS>(p, st)));
+      else TRY((launch_nt<PRO_NONE, EPI_BIAS>(p, st)));
+    } else {
+      p.A = z_cat + d.off[l - 1]; p.lda = ldz; p.W = ly[l].w; p.ldw = ly[l].cin; p.K = ly[l].cin;
+      p.pa = scale + d.off[l - 1]; p.pb = shift + d.off[l - 1];
+      if (training) TRY((launch_nt<PRO_BNRELU, EPI_BIAS_STATS>(p, st)));
+      else TRY((launch_nt<PRO_BNRELU, EPI_BIAS>(p, st)));
+    }
+    TRY(bn_coeffs(ly[l], P, training, momentum, eps, w.ws_a, w.ws_b, mean + d.off[l],
+                  rstd + d.off[l], scale + d.off[l], shift + d.off[l], st));
+  }
+  return PRH_OK;
+}
+
+// Backward through layers L-1..0 of a stack.
+//   dy_cat [P, sum cout] (ld lddy): on entry column block l holds the ReLU-masked gradient
+//   w.r.t. BN_l output coming from OUTSIDE the stack (zero if none) for l < L-1, and the
+//   complete masked gradient for l = L-1.  stats_ready: BN-backward partials of layer L-1
+//   are already in w.ws_a/ws_b.
+// Scratch: coef [3*maxc], wT [max cin*cout], slab, colslab.
+struct StackBwdScratch { float* ca; float* cb; float* cc; float* wT; float* slab; float* colslab; float* dxpad; };
+
+int stack_backward(const prh_bn_layer* ly, int L, const float* x, int P, int training,
+                   float* dy_cat, long lddy, const float* z_cat, long ldz, const float* scale,
+                   const float* shift, const float* mean, const float* rstd,
+                   const prh_bn_layer_grad* gr, float* dx, StackWS& w, StackBwdScratch& sc,
+                   hipStream_t st) {
+  StackDims d = stack_dims(ly, L);
+  const float* x0 = x; long ldx = d.cin0; int k0 = d.cin0;
+  if (d.cin0p != d.cin0) { x0 = w.xpad; ldx = d.cin0p; k0 = d.cin0p; }   // xpad filled by caller
+  for (int l = L - 1; l >= 0; --l) {
+    const int co = ly[l].cout, o = d.off[l];
+    // 1. statistics -> BN-backward coefficients, dgamma, dbeta, dbias
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(co, 32)), dim3(1024), 0, st, w.ws_a,
+                       w.ws_b, stat_tiles(P), P, co, ly[l].gamma, mean + o, rstd + o, training,
+                       sc.ca, sc.cb, sc.cc, gr ? gr[l].dgamma : nullptr, gr ? gr[l].dbeta : nullptr,
+                       gr ? gr[l].db : nullptr);
+    LAUNCH_CHECK();
+    // 2. wgrad: dW_l = dz_l^T h_{l-1}
+    if (gr && gr[l].dw) {
+      TNParams t; memset(&t, 0, sizeof(t));
+      t.A = dy_cat + o; t.lda = lddy; t.A2 = z_cat + o; t.lda2 = ldz;
+      t.P = P; t.Mo = co; t.pa = sc.ca; t.pb = sc.cb; t.pc = sc.cc;
+      if (l == 0) {
+        t.B = x0; t.ldb = ldx; t.Ni = k0;
+        if (k0 == d.cin0) {
+          TRY((launch_tn<PRO_BNBWD, PRO_NONE>(t, sc.slab, sc.colslab, gr[l].dw, (long)k0, nullptr, st)));
+        } else {   // padded input: reduce into scratch, then drop the pad columns
+          TRY((launch_tn<PRO_BNBWD, PRO_NONE>(t, sc.slab, sc.colslab, sc.wT, (long)k0, nullptr, st)));
+          TRY(copy_cols(sc.wT, k0, d.cin0, gr[l].dw, d.cin0, d.cin0, (size_t)co, st));
+        }
+      } else {
+        t.B = z_cat + d.off[l - 1]; t.ldb = ldz; t.Ni = ly[l].cin;
+        t.qa = scale + d.off[l - 1]; t.qb = shift + d.off[l - 1];
+        TRY((launch_tn<PRO_BNBWD, PRO_BNRELU>(t, sc.slab, sc.colslab, gr[l].dw, (long)ly[l].cin, nullptr, st)));
+      }
+    }
+    // 3. dgrad into the previous layer's block (accumulate + mask + its statistics)
+    if (l > 0) {
+      TRY(transpose(ly[l].w, co, ly[l].cin, sc.wT, st));     // wT [cin, cout]
+      NTParams p; memset(&p, 0, sizeof(p));
+      p.A = dy_cat + o; p.lda = lddy; p.A2 = z_cat + o; p.lda2 = ldz;
+      p.pa = sc.ca; p.pb = sc.cb; p.pc = sc.cc;
+      p.W = sc.wT; p.ldw = co; p.M = P; p.N = ly[l].cin; p.K = co;
+      p.C = dy_cat + d.off[l - 1]; p.ldc = lddy;
+      p.E1 = z_cat + d.off[l - 1]; p.lde1 = ldz;
+      p.es = scale + d.off[l - 1]; p.et = shift + d.off[l - 1];
+      p.ws_a = w.ws_a; p.ws_b = w.ws_b;
+      p.flags = F_ACCUM | F_MASK | F_STATS;
+      TRY((launch_nt<PRO_BNBWD, EPI_DGRAD>(p, st)));
+    } else if (dx != nullptr) {
+      // dx = dz_0 W_0  (W_0^T is [cin0p, cout] with zero pad rows)
+      const float* w0 = ly[0].w; int kk = d.cin0;
+      if (d.cin0p != d.cin0) { w0 = w.w0pad; kk = d.cin0p; }
+      TRY(transpose(w0, co, kk, sc.wT, st));
+      NTParams p; memset(&p, 0, sizeof(p));
+      p.A = dy_cat + o; p.lda = lddy; p.A2 = z_cat + o; p.lda2 = ldz;
+      p.pa = sc.ca; p.pb = sc.cb; p.pc = sc.cc;
+      p.W = sc.wT; p.ldw = co; p.M = P; p.N = d.cin0; p.K = co;
+      p.C = dx; p.ldc = d.cin0;
+      p.flags = 0;
+      TRY((launch_nt<PRO_BNBWD, EPI_DGRAD>(p, st)));
+    }
+  }
+  return PRH_OK;
+}
+
+int max_cout(const prh_bn_layer* ly, int L) {
+  int m = 0;
+  for (int l = 0; l < L; ++l) m = ly[l].cout > m ? ly[l].cout : m;
+  return m;
+}
+size_t max_w(const prh_bn_layer* ly, int L) {
+  size_t m = 0;
+  for (int l = 0; l < L; ++l) {
+    size_t s = (size_t)ly[l].cout * align_up((size_t)ly[l].cin, 4);
+    m = s > m ? s : m;
+  }
+  return m;
+}
+void stack_bwd_scratch_carve(Arena& a, StackBwdScratch& sc, int P, const prh_bn_layer* ly, int L,
+                             size_t extra_w, int extra_c) {
+  int mc = max_cout(ly, L); if (extra_c > mc) mc = extra_c;
+  size_t mw = max_w(ly, L); if (extra_w > mw) mw = extra_w;
+  sc.ca = a.f(mc); sc.cb = a.f(mc); sc.cc = a.f(mc);
+  sc.wT = a.f(mw);
+  size_t slab = 0, cs = 0;
+  for (int l = 0; l < L; ++l) {
+    const int ci = (int)align_up((size_t)ly[l].cin, 4);
+    size_t s1 = tn_slab_floats(P, ly[l].cout, ci), s2 = tn_colsum_floats(P, ly[l].cout, ci);
+    slab = s1 > slab ? s1 : slab; cs = s2 > cs ? s2 : cs;
+  }
+  sc.slab = a.f(slab); sc.colslab = a.f(cs);
+}
+
+// ---- workspace layouts of the entry points (measure with Arena(), carve with Arena(ptr,n))
+struct LinearBwdWS { float* wT; float* slab; float* cslab; };
+void linear_bwd_carve(Arena& a, LinearBwdWS& w, int rows, int k, int n) {
+  w.wT = a.f((size_t)k * n);
+  w.slab = a.f(tn_slab_floats(rows, n, k));
+  w.cslab = a.f(tn_colsum_floats(rows, n, k));
+}
+struct MlpWS { StackWS w; StackBwdScratch sc; float* dy_cat; };
+void mlp_carve(Arena& a, MlpWS& m, int P, const prh_bn_layer* ly, int L) {
+  StackDims d = stack_dims(ly, L);
+  stack_ws_carve(a, m.w, P, ly, L, max_cout(ly, L));
+  stack_bwd_scratch_carve(a, m.sc, P, ly, L, 0, 0);
+  m.dy_cat = a.f((size_t)P * d.off[L]);
+}
+struct EncWS { StackWS w; StackBwdScratch sc; float* fslab; float* fcslab; float* dy_cat; float* dU; float* gsum_a; float* gsum_b; };
+void enc_carve(Arena& a, EncWS& e, int P, const prh_bn_layer* conv, int cat, int od, bool backward) {
+  stack_ws_carve(a, e.w, P, conv, 5, cat > od ? cat : od);
+  if (!backward) return;
+  stack_bwd_scratch_carve(a, e.sc, P, conv, 5, (size_t)od * cat, cat > od ? cat : od);
+  const size_t fs = tn_slab_floats(P, od, cat), gs = tn_slab_floats(P, od, 64);
+  const size_t fc = tn_colsum_floats(P, od, cat), gc = tn_colsum_floats(P, od, 64);
+  e.fslab = a.f(fs > gs ? fs : gs);
+  e.fcslab = a.f(fc > gc ? fc : gc);
+  e.dy_cat = a.f((size_t)P * cat);
+  e.dU = a.f((size_t)P * 64);
+  e.gsum_a = a.f(64);
+  e.gsum_b = a.f(64);
+}
+
+}  // namespace
+
+// =======================================================================================
+extern "C" {
+
+const char* prh_last_error(void) { return g_err; }
+const char* prh_version(void) { return "pointnet_refine_hip 0.1 (gfx950, fp32 MFMA 32x32x2)"; }
+
+// ------------------------------------------------------------------ Linear
+int prh_linear_forward(const float* x, long ldx, const float* w, const float* b, float* y,
+                       int rows, int k, int n, int relu, int device, void* stream) {
+  if (!x || !w || !y || rows < 0 || k <= 0 || n <= 0) return fail(PRH_ERR_ARG, "linear_forward: bad argument");
+  HIP_TRY(hipSetDevice(device));
+  NTParams p; memset(&p, 0, sizeof(p));
+  p.A = x; p.lda = ldx; p.W = w; p.ldw = k; p.C = y; p.ldc = n;
+  p.M = rows; p.N = n; p.K = k; p.bias = b; p.flags = relu ? F_RELU_OUT : 0;
+  return launch_nt<PRO_NONE, EPI_BIAS>(p, (hipStream_t)stream);
+}
+
+size_t prh_linear_backward_workspace_bytes(int rows, int k, int n) {
+  Arena a; LinearBwdWS w;
+  linear_bwd_carve(a, w, rows, k, n);
+  return a.off + 256;
+}
+
+int prh_linear_backward(const float* x, long ldx, const float* w, const float* dy, float* dx,
+                        float* dw, float* db, int rows, int k, int n, void* workspace,
+                        size_t workspace_bytes, int device, void* stream) {
+  if (!x || !w || !dy || rows < 0 || k <= 0 || n <= 0) return fail(PRH_ERR_ARG, "linear_backward: bad argument");
+  if ((k & 3) || (n & 3)) return fail(PRH_ERR_ARG, "linear_backward: k=%d and n=%d must be multiples of 4", k, n);
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  Arena a(workspace, workspace_bytes);
+  LinearBwdWS lw;
+  linear_bwd_carve(a, lw, rows, k, n);
+  if (!a.ok) return fail(PRH_ERR_WORKSPACE, "linear_backward: workspace too small (%zu bytes)", workspace_bytes);
+  float *wT = lw.wT, *slab = lw.slab, *cslab = lw.cslab;
+  if (dx != nullptr) {
+    TRY(transpose(w, n, k, wT, st));   // wT [k, n]
+    NTParams p; memset(&p, 0, sizeof(p));
+    p.A = dy; p.lda = n; p.W = wT; p.ldw = n; p.C = dx; p.ldc = k; p.M = rows; p.N = k; p.K = n;
+    TRY((launch_nt<PRO_NONE, EPI_BIAS>(p, st)));
+  }
+  if (dw != nullptr || db != nullptr) {
+    TNParams t; memset(&t, 0, sizeof(t));
+    t.A = dy; t.lda = n; t.B = x; t.ldb = ldx; t.P = rows; t.Mo = n; t.Ni = k;
+    TRY((launch_tn<PRO_NONE, PRO_NONE>(t, slab, cslab, dw, (long)k, db, st)));
+  }
+  return PRH_OK;
+}
+
+// ------------------------------------------------------------------ MLP stack (point_mlp)
+size_t prh_mlp_stack_workspace_bytes(int P, int n_layers, const prh_bn_layer* layers) {
+  if (n_layers < 1 || n_layers > PRH_MAX_LAYERS) return 0;
+  Arena a; MlpWS m;
+  mlp_carve(a, m, P, layers, n_layers);
+  return a.off + 256;
+}
+
+int prh_mlp_stack_forward(const prh_bn_layer* layers, int n_layers, int relu_last,
+                          const float* x, int P, int training, float momentum, float eps,
+                          float* z_cat, float* y, float* bn_scale, float* bn_shift,
+                          float* bn_mean, float* bn_rstd, void* workspace,
+                          size_t workspace_bytes, int device, void* stream) {
+  TRY(check_stack(layers, n_layers));
+  if (!x || !z_cat || !y || !bn_scale || !bn_shift || !bn_mean || !bn_rstd || P <= 0)
+    return fail(PRH_ERR_ARG, "mlp_stack_forward: bad argument");
+  if (training && P < 2) return fail(PRH_ERR_ARG, "Expected more than 1 value per channel when training");
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  StackDims d = stack_dims(layers, n_layers);
+  Arena a(workspace, workspace_bytes);
+  MlpWS m;
+  mlp_carve(a, m, P, layers, n_layers);
+  if (!a.ok) return fail(PRH_ERR_WORKSPACE, "mlp_stack_forward: workspace too small (%zu bytes)", workspace_bytes);
+  StackWS& w = m.w;
+  const long ldz = d.off[n_layers];
+  TRY(stack_forward(layers, n_layers, x, P, training, momentum, eps, z_cat, ldz, bn_scale,
+                    bn_shift, bn_mean, bn_rstd, w, st));
+  const int L = n_layers, co = layers[L - 1].cout;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(cdiv(P, 64), cdiv(co, 64)), dim3(256), 0, st,
+                     z_cat + d.off[L - 1], ldz, bn_scale + d.off[L - 1], bn_shift + d.off[L - 1], P,
+                     co, relu_last, y, (long)co);
+  LAUNCH_CHECK();
+  return PRH_OK;
+}
+
+int prh_mlp_stack_backward(const prh_bn_layer* layers, int n_layers, int relu_last,
+                           const float* x, int P, int training, const float* dy,
+                           const float* z_cat, const float* bn_scale, const float* bn_shift,
+                           const float* bn_mean, const float* bn_rstd,
+                           const prh_bn_layer_grad* grads, float* dx, void* workspace,
+                           size_t workspace_bytes, int device, void* stream) {
+  TRY(check_stack(layers, n_layers));
+  if (!x || !dy || !z_cat || P <= 0) return fail(PRH_ERR_ARG, "mlp_stack_backward: bad argument");
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  StackDims d = stack_dims(layers, n_layers);
+  const int L = n_layers;
+  Arena a(workspace, workspace_bytes);
+  MlpWS m;
+  mlp_carve(a, m, P, layers, L);
+  StackWS& w = m.w;
+  StackBwdScratch& sc = m.sc;
+  const long ldz = d.off[L];
+  float* dy_cat = m.dy_cat;
+  if (!a.ok) return fail(PRH_ERR_WORKSPACE, "mlp_stack_backward: workspace too small (%zu bytes)", workspace_bytes);
+  if (d.cin0p != d.cin0) {
+    TRY(copy_cols(x, d.cin0, d.cin0, w.xpad, d.cin0p, d.cin0p, (size_t)P, st));
+    TRY(copy_cols(layers[0].w, d.cin0, d.cin0, w.w0pad, d.cin0p, d.cin0p, (size_t)layers[0].cout, st));
+  }
+  if (L > 1) HIP_TRY(hipMemsetAsync(dy_cat, 0, (size_t)P * ldz * sizeof(float), st));
+  const int co = layers[L - 1].cout, o = d.off[L - 1];
+  hipLaunchKernelGGL(bn_dy_stats_kernel, dim3(cdiv(P, 64), cdiv(co, 64)), dim3(256), 0, st, dy,
+                     (long)co, z_cat + o, ldz, bn_scale + o, bn_shift + o, P, co, relu_last,
+                     dy_cat + o, ldz, w.ws_a, w.ws_b);
+  LAUNCH_CHECK();
+  // ws partial count of the elementwise kernel is cdiv(P,64); pad entry (if any) of the
+  // GEMM-shaped count must read as zero
+  if (stat_tiles(P) > cdiv(P, 64)) {
+    HIP_TRY(hipMemsetAsync(w.ws_a + (size_t)cdiv(P, 64) * co, 0, (size_t)co * sizeof(float), st));
+    HIP_TRY(hipMemsetAsync(w.ws_b + (size_t)cdiv(P, 64) * co, 0, (size_t)co * sizeof(float), st));
+  }
+  return stack_backward(layers, L, x, P, training, dy_cat, ldz, z_cat, ldz, bn_scale, bn_shift,
+                        bn_mean, bn_rstd, grads, dx, w, sc, st);
+}
+
+// ------------------------------------------------------------------ encoder
+static int enc_cat(const prh_encoder_params* prm) {
+  int c = 0;
+  for (int l = 0; l < 5; ++l) c += prm->conv[l].cout;
+  return c;
+}
+
+size_t prh_encoder_workspace_bytes(int B, int N, int in_channel, int out_dim, int backward) {
+  const int P = B * N;
+  prh_bn_layer ly[5];
+  const int ch[6] = {in_channel, 64, 128, 256, 512, out_dim};
+  for (int l = 0; l < 5; ++l) { ly[l].cin = ch[l]; ly[l].cout = ch[l + 1]; }
+  const int cat = 64 + 128 + 256 + 512 + out_dim;
+  Arena a; EncWS e;
+  enc_carve(a, e, P, ly, cat, out_dim, backward != 0);
+  return a.off + 256;
+}
+
+static int check_encoder(const prh_encoder_params* prm) {
+  if (!prm) return fail(PRH_ERR_ARG, "encoder: null params");
+  if (prm->in_channel < 4) return fail(PRH_ERR_ARG, "encoder: expected input to have at least 4 channels (x,y,z,intensity), got %d", prm->in_channel);
+  if (prm->conv[0].cin != prm->in_channel) return fail(PRH_ERR_ARG, "encoder: conv1.cin != in_channel");
+  TRY(check_stack(prm->conv, 5));
+  if (prm->conv[4].cout != prm->out_dim) return fail(PRH_ERR_ARG, "encoder: conv5.cout != out_dim");
+  if (prm->fusion.cin != enc_cat(prm) || prm->fusion.cout != prm->out_dim)
+    return fail(PRH_ERR_ARG, "encoder: fusion layer shape mismatch");
+  if (prm->out_dim % 4) return fail(PRH_ERR_ARG, "encoder: out_dim must be a multiple of 4");
+  if (!prm->fusion.w || !prm->fusion.b || !prm->fusion.gamma || !prm->fusion.beta ||
+      !prm->fusion.running_mean || !prm->fusion.running_var || !prm->gate_w1 || !prm->gate_b1 ||
+      !prm->gate_w2 || !prm->gate_b2)
+    return fail(PRH_ERR_ARG, "encoder: null parameter pointer");
+  return PRH_OK;
+}
+
+int prh_encoder_forward(const prh_encoder_params* prm, const float* ctx, int B, int N,
+                        int training, float momentum, float eps, float* fused, float* gfeat,
+                        const prh_encoder_saved* sv, void* workspace, size_t workspace_bytes,
+                        int device, void* stream) {
+  TRY(check_encoder(prm));
+  if (!ctx || !fused || !sv || !sv->z_cat || !sv->z_fus || !sv->bn_scale || !sv->bn_shift ||
+      !sv->bn_mean || !sv->bn_rstd || B <= 0 || N <= 0)
+    return fail(PRH_ERR_ARG, "encoder_forward: bad argument");
+  if ((long)B * N > 2000000000L) return fail(PRH_ERR_ARG, "encoder_forward: B*N too large");
+  const int P = B * N;
+  if (training && P < 2) return fail(PRH_ERR_ARG, "Expected more than 1 value per channel when training");
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  const int cat = enc_cat(prm), od = prm->out_dim, C = prm->in_channel;
+  Arena a(workspace, workspace_bytes);
+  EncWS ews;
+  enc_carve(a, ews, P, prm->conv, cat, od, false);
+  if (!a.ok) return fail(PRH_ERR_WORKSPACE, "encoder_forward: workspace too small (%zu bytes)", workspace_bytes);
+  StackWS& w = ews.w;
+
+  // conv1..5 (+bn, relu applied on load by the consumer)           src/model.py:43-47
+  TRY(stack_forward(prm->conv, 5, ctx, P, training, momentum, eps, sv->z_cat, (long)cat,
+                    sv->bn_scale, sv->bn_shift, sv->bn_mean, sv->bn_rstd, w, st));
+  // fusion conv over the (never materialised) concat               src/model.py:50-51
+  {
+    NTParams p; memset(&p, 0, sizeof(p));
+    p.A = sv->z_cat; p.lda = cat; p.W = prm->fusion.w; p.ldw = cat; p.K = cat;
+    p.pa = sv->bn_scale; p.pb = sv->bn_shift;
+    p.M = P; p.N = od; p.bias = prm->fusion.b; p.C = sv->z_fus; p.ldc = od;
+    p.ws_a = w.ws_a; p.ws_b = w.ws_b;
+    if (training) TRY((launch_nt<PRO_BNRELU, EPI_BIAS_STATS>(p, st)));
+    else TRY((launch_nt<PRO_BNRELU, EPI_BIAS>(p, st)));
+    TRY(bn_coeffs(prm->fusion, P, training, momentum, eps, w.ws_a, w.ws_b, sv->bn_mean + cat,
+                  sv->bn_rstd + cat, sv->bn_scale + cat, sv->bn_shift + cat, st));
+  }
+  // intensity gate GEMM + BN/ReLU/gate combine                     src/model.py:42,51,54-55
+  {
+    NTParams p; memset(&p, 0, sizeof(p));
+    p.A = ctx + 3; p.lda = C; p.pa = prm->gate_w1; p.pb = prm->gate_b1;
+    p.W = prm->gate_w2; p.ldw = 64; p.K = 64; p.M = P; p.N = od; p.bias = prm->gate_b2;
+    p.E1 = sv->z_fus; p.lde1 = od; p.es = sv->bn_scale + cat; p.et = sv->bn_shift + cat;
+    p.C = fused; p.ldc = od; p.C2 = sv->gate; p.ldc2 = od;
+    p.flags = sv->gate ? F_STORE_GATE : 0;
+    TRY((launch_nt<PRO_GATE1, EPI_GATE>(p, st)));
+  }
+  // dual pooling                                                   src/model.py:58-60
+  if (gfeat != nullptr) {
+    hipLaunchKernelGGL(pool_kernel, dim3(cdiv(od, 64), B), dim3(256), 0, st, fused, N, od, gfeat,
+                       sv->argmax);
+    LAUNCH_CHECK();
+  }
+  return PRH_OK;
+}
+
+int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B, int N,
+                         int training, float* d_fused, const float* d_gfeat,
+                         const prh_encoder_saved* sv, const prh_encoder_grads* gr, float* d_ctx,
+                         void* workspace, size_t workspace_bytes, int device, void* stream) {
+  TRY(check_encoder(prm));
+  if (!ctx || !sv || !gr || !sv->z_cat || !sv->z_fus || !sv->gate || !d_fused || B <= 0 || N <= 0)
+    return fail(PRH_ERR_ARG, "encoder_backward: bad argument (d_fused buffer and saved.gate are required)");
+  if (d_gfeat && !sv->argmax) return fail(PRH_ERR_ARG, "encoder_backward: d_gfeat needs saved.argmax");
+  const int P = B * N;
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  const int cat = enc_cat(prm), od = prm->out_dim, C = prm->in_channel;
+  Arena a(workspace, workspace_bytes);
+  EncWS ews;
+  enc_carve(a, ews, P, prm->conv, cat, od, true);
+  StackWS& w = ews.w;
+  StackBwdScratch& sc = ews.sc;
+  float *fslab = ews.fslab, *fcslab = ews.fcslab, *dy_cat = ews.dy_cat, *dU = ews.dU;
+  float *gsum_a = ews.gsum_a, *gsum_b = ews.gsum_b;
+  if (!a.ok) return fail(PRH_ERR_WORKSPACE, "encoder_backward: workspace too small (%zu bytes)", workspace_bytes);
+  StackDims d = stack_dims(prm->conv, 5);
+  if (d.cin0p != d.cin0) {
+    TRY(copy_cols(ctx, d.cin0, d.cin0, w.xpad, d.cin0p, d.cin0p, (size_t)P, st));
+    TRY(copy_cols(prm->conv[0].w, d.cin0, d.cin0, w.w0pad, d.cin0p, d.cin0p, (size_t)prm->conv[0].cout, st));
+  }
+
+  // (1) through F = relu(bn(zf)) * m and the pooling: dy_f -> d_fused (in place),
+  //     dG -> saved.gate (in place), fusion-BN backward partials
+  hipLaunchKernelGGL(combine_bwd_kernel, dim3(cdiv(P, 64), cdiv(od, 64)), dim3(256), 0, st, d_fused,
+                     d_gfeat, sv->argmax, sv->z_fus, sv->gate, sv->bn_scale + cat,
+                     sv->bn_shift + cat, P, N, od, d_fused, w.ws_a, w.ws_b);
+  LAUNCH_CHECK();
+  if (stat_tiles(P) > cdiv(P, 64)) {
+    HIP_TRY(hipMemsetAsync(w.ws_a + (size_t)cdiv(P, 64) * od, 0, (size_t)od * sizeof(float), st));
+    HIP_TRY(hipMemsetAsync(w.ws_b + (size_t)cdiv(P, 64) * od, 0, (size_t)od * sizeof(float), st));
+  }
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(od, 32)), dim3(1024), 0, st, w.ws_a, w.ws_b,
+                     stat_tiles(P), P, od, prm->fusion.gamma, sv->bn_mean + cat, sv->bn_rstd + cat,
+                     training, sc.ca, sc.cb, sc.cc, gr->fusion.dgamma, gr->fusion.dbeta,
+                     gr->fusion.db);
+  LAUNCH_CHECK();
+  float* dG = sv->gate;
+
+  // (2) fusion conv: wgrad over the virtual concat, dgrad into dy_cat (masked per layer),
+  //     with layer-5 BN-backward partials (the only block that is complete here)
+  if (gr->fusion.dw) {
+    TNParams t; memset(&t, 0, sizeof(t));
+    t.A = d_fused; t.lda = od; t.A2 = sv->z_fus; t.lda2 = od; t.pa = sc.ca; t.pb = sc.cb; t.pc = sc.cc;
+    t.B = sv->z_cat; t.ldb = cat; t.qa = sv->bn_scale; t.qb = sv->bn_shift;
+    t.P = P; t.Mo = od; t.Ni = cat;
+    TRY((launch_tn<PRO_BNBWD, PRO_BNRELU>(t, fslab, fcslab, gr->fusion.dw, (long)cat, nullptr, st)));
+  }
+  {
+    TRY(transpose(prm->fusion.w, od, cat, sc.wT, st));   // [cat, od]
+    NTParams p; memset(&p, 0, sizeof(p));
+    p.A = d_fused; p.lda = od; p.A2 = sv->z_fus; p.lda2 = od; p.pa = sc.ca; p.pb = sc.cb; p.pc = sc.cc;
+    p.W = sc.wT; p.ldw = od; p.M = P; p.N = cat; p.K = od;
+    p.C = dy_cat; p.ldc = cat; p.E1 = sv->z_cat; p.lde1 = cat; p.es = sv->bn_scale; p.et = sv->bn_shift;
+    p.flags = F_MASK;
+    TRY((launch_nt<PRO_BNBWD, EPI_DGRAD>(p, st)));
+  }
+  // layer-5 partials: its block of dy_cat is final (no later conv feeds on it)
+  {
+    const int o5 = d.off[4], c5 = prm->conv[4].cout;
+    hipLaunchKernelGGL(bn_dy_stats_kernel, dim3(cdiv(P, 64), cdiv(c5, 64)), dim3(256), 0, st,
+                       dy_cat + o5, (long)cat, sv->z_cat + o5, (long)cat, sv->bn_scale + o5,
+                       sv->bn_shift + o5, P, c5, 0, dy_cat + o5, (long)cat, w.ws_a, w.ws_b);
+    LAUNCH_CHECK();
+    if (stat_tiles(P) > cdiv(P, 64)) {
+      HIP_TRY(hipMemsetAsync(w.ws_a + (size_t)cdiv(P, 64) * c5, 0, (size_t)c5 * sizeof(float), st));
+      HIP_TRY(hipMemsetAsync(w.ws_b + (size_t)cdiv(P, 64) * c5, 0, (size_t)c5 * sizeof(float), st));
+    }
+  }
+  // (3) conv5..conv1
+  float* dx = d_ctx;
+  TRY(stack_backward(prm->conv, 5, ctx, P, training, dy_cat, (long)cat, sv->z_cat, (long)cat,
+                     sv->bn_scale, sv->bn_shift, sv->bn_mean, sv->bn_rstd, gr->conv, dx, w, sc, st));
+
+  // (4) intensity gate: dW2 = dG^T u, db2 = colsum dG; dU = dG W2 masked by u>0 with
+  //     column sums (db1) and intensity-weighted column sums (dw1)
+  {
+    TNParams t; memset(&t, 0, sizeof(t));
+    t.A = dG; t.lda = od; t.B = ctx + 3; t.ldb = C; t.qa = prm->gate_w1; t.qb = prm->gate_b1;
+    t.P = P; t.Mo = od; t.Ni = 64;
+    TRY((launch_tn<PRO_NONE, PRO_GATE1>(t, fslab, fcslab, gr->d_gate_w2, 64L, gr->d_gate_b2, st)));
+    TRY(transpose(prm->gate_w2, od, 64, sc.wT, st));   // [64, od]
+    NTParams p; memset(&p, 0, sizeof(p));
+    p.A = dG; p.lda = od; p.W = sc.wT; p.ldw = od; p.M = P; p.N = 64; p.K = od;
+    p.C = dU; p.ldc = 64; p.E1 = ctx + 3; p.lde1 = C; p.es = prm->gate_w1; p.et = prm->gate_b1;
+    p.ws_a = w.ws_a; p.ws_b = w.ws_b;
+    p.flags = F_MASK | F_STATS | F_E1_ROWVEC;
+    TRY((launch_nt<PRO_NONE, EPI_DGRAD>(p, st)));
+    hipLaunchKernelGGL(partials_reduce_kernel, dim3(2), dim3(1024), 0, st, w.ws_a, w.ws_b,
+                       stat_tiles(P), 64, gr->d_gate_b1 ? gr->d_gate_b1 : gsum_a,
+                       gr->d_gate_w1 ? gr->d_gate_w1 : gsum_b);
+    LAUNCH_CHECK();
+    if (d_ctx != nullptr) {
+      hipLaunchKernelGGL(gate1_dctx_kernel, dim3(cdiv(P, 4)), dim3(256), 0, st, dU, P, 64,
+                         prm->gate_w1, d_ctx, (long)C);
+      LAUNCH_CHECK();
+    }
+  }
+  return PRH_OK;
+}
+
+// ------------------------------------------------------------------ raw cores for tests
+int prh_test_gemm_nt(const float* a, const float* w, float* c, int m, int n, int k, int device,
+                     void* stream) {
+  HIP_TRY(hipSetDevice(device));
+  NTParams p; memset(&p, 0, sizeof(p));
+  p.A = a; p.lda = k; p.W = w; p.ldw = k; p.C = c; p.ldc = n; p.M = m; p.N = n; p.K = k;
+  return launch_nt<PRO_NONE, EPI_BIAS>(p, (hipStream_t)stream);
+}
+size_t prh_test_gemm_tn_workspace_bytes(int p, int mo, int ni) {
+  Arena a;
+  a.f(tn_slab_floats(p, mo, ni));
+  a.f(tn_colsum_floats(p, mo, ni));
+  return a.off + 256;
+}
+int prh_test_gemm_tn(const float* a, const float* b, float* c, float* colsum, int p, int mo, int ni,
+                     void* workspace, size_t workspace_bytes, int device, void* stream) {
+  HIP_TRY(hipSetDevice(device));
+  Arena ar(workspace, workspace_bytes);
+  float* slab = ar.f(tn_slab_floats(p, mo, ni));
+  float* cs = ar.f(tn_colsum_floats(p, mo, ni));
+  if (!ar.ok) return fail(PRH_ERR_WORKSPACE, "test_gemm_tn: workspace too small");
+  TNParams t; memset(&t, 0, sizeof(t));
+  t.A = a; t.lda = mo; t.B = b; t.ldb = ni; t.P = p; t.Mo = mo; t.Ni = ni;
+  return launch_tn<PRO_NONE, PRO_NONE>(t, slab, cs, c, (long)ni, colsum, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,194 @@
+"""Drop-in nn.Module surface of the reference's ``src/model.py`` on the MI355X HIP path.
+
+Same class names, constructor signatures, ``forward`` contracts and ``state_dict`` (205
+entries, names/shapes/dtypes of ``/root/reference/src/model.py``), so the reference's
+``train.py`` / ``train_dist.py`` / ``inference_whole_scene.py`` work after replacing
+``from src.model import LineRefineNet`` with ``from pointnet_refine_amd.model import
+LineRefineNet`` and a strict ``load_state_dict`` of a reference checkpoint succeeds.
+
+The submodules (``nn.Conv1d``, ``nn.BatchNorm1d``, ``nn.Linear`` ...) exist as PARAMETER
+CONTAINERS with the reference's names and default initialisation; the arithmetic of the
+accelerated rows (a1-a6) does not go through them but through
+``ops.py`` -> C ABI -> hand-written gfx950 kernels:
+
+  a1-a4  MultiScalePointNetEncoder   ops.encoder        (src/model.py:39-62)
+  a5     context_proj                ops.linear         (src/model.py:147,194)
+  a6     point_mlp                   ops.mlp_stack      (src/model.py:150-159,200-201)
+
+Rows a7-a10 (regression heads, positional encoding, DETR decoder) run on stock
+PyTorch-ROCm modules for now (SURVEY.md section 8f "next").
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+def _bn_buffers(bn: nn.BatchNorm1d):
+    return [bn.running_mean, bn.running_var, bn.num_batches_tracked]
+
+
+class MultiScalePointNetEncoder(nn.Module):
+    """Multi-scale PointNet encoder with dual pooling (reference: src/model.py:5-62)."""
+
+    def __init__(self, in_channel=4, out_dim=1024):
+        super().__init__()
+        self.conv1 = nn.Conv1d(in_channel, 64, 1)
+        self.conv2 = nn.Conv1d(64, 128, 1)
+        self.conv3 = nn.Conv1d(128, 256, 1)
+        self.conv4 = nn.Conv1d(256, 512, 1)
+        self.conv5 = nn.Conv1d(512, out_dim, 1)
+        self.bn1 = nn.BatchNorm1d(64)
+        self.bn2 = nn.BatchNorm1d(128)
+        self.bn3 = nn.BatchNorm1d(256)
+        self.bn4 = nn.BatchNorm1d(512)
+        self.bn5 = nn.BatchNorm1d(out_dim)
+        self.fusion = nn.Sequential(
+            nn.Conv1d(64 + 128 + 256 + 512 + out_dim, out_dim, 1),
+            nn.BatchNorm1d(out_dim),
+            nn.ReLU(),
+        )
+        self.intensity_gate = nn.Sequential(
+            nn.Conv1d(1, 64, 1),
+            nn.ReLU(),
+            nn.Conv1d(64, out_dim, 1),
+            nn.Sigmoid(),
+        )
+        self.in_channel = in_channel
+        self.out_dim = out_dim
+
+    def _param_list(self):
+        sd = dict(self.named_parameters())
+        return [sd[k] for k in ops.ENC_PARAM_ORDER]
+
+    def _bn_buffer_list(self):
+        b = []
+        for bn in (self.bn1, self.bn2, self.bn3, self.bn4, self.bn5, self.fusion[1]):
+            b += _bn_buffers(bn)
+        return b
+
+    def forward_pointmajor(self, x_pm: torch.Tensor, want_global: bool = True):
+        """x_pm (B,N,C) contiguous point-major -> (global_feat (B,2*out) or None,
+        fused (B,N,out)).  The layout the kernels use; LineRefineNet calls this directly
+        and skips the pooling it would discard (src/model.py:193)."""
+        if x_pm.dim() != 3:
+            raise RuntimeError(f"Expected 3D (batched) input, but got input of size: {list(x_pm.shape)}")
+        bn = self.bn1
+        return ops.encoder(x_pm, self._param_list(), self._bn_buffer_list(), want_global, self.training,
+                           bn.momentum, bn.eps)
+
+    def forward(self, x):
+        """x: (B, C, N), C = 4 -> [x, y, z, intensity].  Returns (global_feat (B, 2*out_dim),
+        fused (B, out_dim, N)) exactly like the reference (src/model.py:39-62)."""
+        if x.dim() != 3:
+            raise RuntimeError(f"Expected 3D (batched) input, but got input of size: {list(x.shape)}")
+        gfeat, fused = self.forward_pointmajor(x.transpose(2, 1).contiguous(), True)
+        return gfeat, fused.transpose(2, 1)
+
+
+class PositionalEncoding(nn.Module):
+    """MLP positional encoding for 3-D coordinates (reference: src/model.py:64-75)."""
+
+    def __init__(self, in_dim=3, out_dim=256):
+        super().__init__()
+        self.mlp = nn.Sequential(nn.Linear(in_dim, out_dim), nn.ReLU(), nn.Linear(out_dim, out_dim))
+
+    def forward(self, xyz):
+        return self.mlp(xyz)
+
+
+class DetrTransformerDecoderLayer(nn.Module):
+    """Post-norm DETR decoder layer (reference: src/model.py:77-135)."""
+
+    def __init__(self, d_model=256, nhead=8, dim_feedforward=1024, dropout=0.1):
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout, batch_first=True)
+        self.cross_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout, batch_first=True)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.norm3 = nn.LayerNorm(d_model)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.dropout3 = nn.Dropout(dropout)
+        self.activation = F.relu
+
+    def with_pos_embed(self, tensor, pos):
+        return tensor if pos is None else tensor + pos
+
+    def forward(self, tgt, memory, query_pos=None, pos=None):
+        q = k = self.with_pos_embed(tgt, query_pos)
+        tgt2 = self.self_attn(q, k, value=tgt)[0]
+        tgt = self.norm1(tgt + self.dropout1(tgt2))
+        q = self.with_pos_embed(tgt, query_pos)
+        k = self.with_pos_embed(memory, pos)
+        tgt2 = self.cross_attn(q, k, value=memory)[0]
+        tgt = self.norm2(tgt + self.dropout2(tgt2))
+        tgt2 = self.linear2(self.dropout(self.activation(self.linear1(tgt))))
+        tgt = self.norm3(tgt + self.dropout3(tgt2))
+        return tgt
+
+
+class LineRefineNet(nn.Module):
+    """Reference: src/model.py:137-234.  forward(context (B,N,4), noisy_line (B,M,3)) ->
+    (6,B,M,3) cumulative offsets per decoder layer."""
+
+    def __init__(self, num_line_points=32, feature_dim=1024):
+        super().__init__()
+        self.d_model = 256
+        self.num_decoder_layers = 6
+        self.context_encoder = MultiScalePointNetEncoder(in_channel=4, out_dim=feature_dim)
+        self.context_proj = nn.Linear(feature_dim, self.d_model)
+        self.point_mlp = nn.Sequential(
+            nn.Conv1d(3, 64, 1), nn.BatchNorm1d(64), nn.ReLU(),
+            nn.Conv1d(64, 128, 1), nn.BatchNorm1d(128), nn.ReLU(),
+            nn.Conv1d(128, self.d_model, 1), nn.BatchNorm1d(self.d_model),
+        )
+        self.pos_emb = PositionalEncoding(in_dim=3, out_dim=self.d_model)
+        self.decoder_layers = nn.ModuleList([
+            DetrTransformerDecoderLayer(d_model=self.d_model, nhead=8, dim_feedforward=1024)
+            for _ in range(self.num_decoder_layers)
+        ])
+        self.reg_branches = nn.ModuleList([
+            nn.Sequential(nn.Linear(self.d_model, 128), nn.ReLU(), nn.Linear(128, 3))
+            for _ in range(self.num_decoder_layers)
+        ])
+
+    # -- accelerated rows -------------------------------------------------------------------
+    def encode_context(self, context):
+        """context (B,N,4) -> memory (B,N,256): encoder + context_proj (src/model.py:192-194)."""
+        _, fused = self.context_encoder.forward_pointmajor(context, want_global=False)
+        return ops.linear(fused, self.context_proj.weight, self.context_proj.bias)
+
+    def encode_line(self, noisy_line):
+        """noisy_line (B,M,3) -> initial queries (B,M,256): point_mlp (src/model.py:200-201)."""
+        B, M, _ = noisy_line.shape
+        pm = self.point_mlp
+        layers = [(pm[0].weight, pm[0].bias, pm[1].weight, pm[1].bias),
+                  (pm[3].weight, pm[3].bias, pm[4].weight, pm[4].bias),
+                  (pm[6].weight, pm[6].bias, pm[7].weight, pm[7].bias)]
+        buffers = _bn_buffers(pm[1]) + _bn_buffers(pm[4]) + _bn_buffers(pm[7])
+        y = ops.mlp_stack(noisy_line.reshape(B * M, -1), layers, buffers, relu_last=False,
+                          training=self.training, momentum=pm[1].momentum, eps=pm[1].eps)
+        return y.reshape(B, M, -1)
+
+    def forward(self, context, noisy_line):
+        if context.dim() != 3 or noisy_line.dim() != 3:
+            raise RuntimeError("LineRefineNet expects context (B,N,4) and noisy_line (B,M,3)")
+        memory = self.encode_context(context)                       # (B, N, 256)
+        pos_mem = self.pos_emb(context[:, :, :3])                   # (B, N, 256)
+        tgt = self.encode_line(noisy_line)                          # (B, M, 256)
+        current_line_coords = noisy_line.clone()
+        all_pred_offsets = []
+        for decoder_layer, reg_branch in zip(self.decoder_layers, self.reg_branches):
+            pos_tgt = self.pos_emb(current_line_coords)
+            tgt = decoder_layer(tgt, memory, query_pos=pos_tgt, pos=pos_mem)
+            delta_offset = reg_branch(tgt)
+            current_line_coords = current_line_coords + delta_offset      # no detach (H5)
+            all_pred_offsets.append(current_line_coords - noisy_line)
+        return torch.stack(all_pred_offsets)

@@ -1,0 +1,319 @@
+"""torch.autograd.Functions over the C ABI (``include/pointnet_refine_hip.h``).
+
+PyTorch is plumbing here: it owns device memory, streams and the autograd graph; all
+arithmetic of the shared-MLP path runs in the HIP library.  Every op raises on non-GPU
+tensors - there is no CPU or eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+_workspaces = {}
+
+
+def _ws(device: torch.device, nbytes: int) -> torch.Tensor:
+    """Grow-only scratch buffer per device.  Safe to reuse across calls because all work
+    of one device is enqueued on its current stream in program order."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    t = _workspaces.get(key)
+    if t is None or t.numel() < nbytes:
+        _workspaces.pop(key, None)
+        t = None
+        t = torch.empty(int(nbytes * 1.05) + 4096, dtype=torch.uint8, device=device)
+        _workspaces[key] = t
+    return t
+
+
+def release_workspaces():
+    _workspaces.clear()
+
+
+def _stream(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _req_gpu_f32(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"pointnet_refine_amd: {name} must be a GPU tensor (got {t.device}); "
+                           "the HIP path has no CPU fallback")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"pointnet_refine_amd: {name} must be float32 (got {t.dtype})")
+
+
+def _bn_layer(w, b, g, beta, rm, rv, nbt) -> L.BnLayer:
+    cout, cin = w.shape[0], w.shape[1]
+    return L.BnLayer(_p(w), _p(b), _p(g), _p(beta), _p(rm), _p(rv), _p(nbt), cin, cout)
+
+
+# ------------------------------------------------------------------------------------------
+# nn.Linear
+# ------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b on the fp32 MFMA GEMM core (context_proj, src/model.py:147,194)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _req_gpu_f32(x, "input")
+        _req_gpu_f32(w, "weight")
+        n, k = w.shape
+        if x.shape[-1] != k:
+            raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({x.shape} and {k}x{n})")
+        if k % 4:
+            raise RuntimeError("pointnet_refine_amd.linear: in_features must be a multiple of 4")
+        x2 = x.reshape(-1, k)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        w = w.contiguous()
+        rows = x2.shape[0]
+        y = torch.empty((rows, n), dtype=torch.float32, device=x.device)
+        L.check(L.lib().prh_linear_forward(_p(x2), k, _p(w), _p(b), _p(y), rows, k, n, 0,
+                                           x.device.index, _stream(x.device)), "prh_linear_forward")
+        ctx.save_for_backward(x2, w)
+        ctx.has_bias = b is not None
+        ctx.xshape = x.shape
+        return y.reshape(*x.shape[:-1], n)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        n, k = w.shape
+        rows = x2.shape[0]
+        if n % 4:
+            raise RuntimeError("pointnet_refine_amd.linear backward: out_features must be a multiple of 4")
+        dy2 = dy.reshape(rows, n)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dev = x2.device
+        need_dx, need_dw, need_db = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        dx = torch.empty_like(x2) if need_dx else None
+        dw = torch.empty_like(w) if need_dw else None
+        db = torch.empty(n, dtype=torch.float32, device=dev) if need_db else None
+        nb = L.lib().prh_linear_backward_workspace_bytes(rows, k, n)
+        ws = _ws(dev, nb)
+        L.check(L.lib().prh_linear_backward(_p(x2), k, _p(w), _p(dy2), _p(dx), _p(dw), _p(db), rows,
+                                            k, n, _p(ws), ws.numel(), dev.index, _stream(dev)),
+                "prh_linear_backward")
+        return (dx.reshape(ctx.xshape) if need_dx else None), dw, db
+
+
+def linear(x, w, b=None):
+    return LinearFn.apply(x, w, b)
+
+
+# ------------------------------------------------------------------------------------------
+# Shared-MLP stack (Conv1d k=1 + BatchNorm1d [+ ReLU]) x L    -- point_mlp
+# ------------------------------------------------------------------------------------------
+class MlpStackFn(torch.autograd.Function):
+    """x (P,cin) -> y (P,cout_last).  params = [w,b,gamma,beta]*L (w as (cout,cin)),
+    buffers = [running_mean, running_var, num_batches_tracked]*L (updated in train mode)."""
+
+    @staticmethod
+    def forward(ctx, x, relu_last, training, momentum, eps, buffers, *params):
+        _req_gpu_f32(x, "input")
+        nl = len(params) // 4
+        dev = x.device
+        x = x.contiguous()
+        P = x.shape[0]
+        ws_ = [params[4 * l].reshape(params[4 * l].shape[0], -1).contiguous() for l in range(nl)]
+        if x.shape[1] != ws_[0].shape[1]:
+            raise RuntimeError(f"expected input to have {ws_[0].shape[1]} channels, but got {x.shape[1]} channels instead")
+        if training and P < 2:
+            raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")
+        layers = (L.BnLayer * nl)()
+        for l in range(nl):
+            _req_gpu_f32(ws_[l], "weight")
+            layers[l] = _bn_layer(ws_[l], params[4 * l + 1], params[4 * l + 2], params[4 * l + 3],
+                                  buffers[3 * l], buffers[3 * l + 1], buffers[3 * l + 2])
+        ctot = sum(w.shape[0] for w in ws_)
+        z_cat = torch.empty((P, ctot), dtype=torch.float32, device=dev)
+        y = torch.empty((P, ws_[-1].shape[0]), dtype=torch.float32, device=dev)
+        coef = torch.empty((4, ctot), dtype=torch.float32, device=dev)
+        nb = L.lib().prh_mlp_stack_workspace_bytes(P, nl, layers)
+        ws = _ws(dev, nb)
+        L.check(L.lib().prh_mlp_stack_forward(layers, nl, int(relu_last), _p(x), P, int(training),
+                                              float(momentum), float(eps), _p(z_cat), _p(y),
+                                              _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]),
+                                              _p(ws), ws.numel(), dev.index, _stream(dev)),
+                "prh_mlp_stack_forward")
+        ctx.save_for_backward(x, z_cat, coef, *ws_, *[params[4 * l + 2] for l in range(nl)])
+        ctx.nl, ctx.relu_last, ctx.training = nl, int(relu_last), int(training)
+        ctx.wshapes = [params[4 * l].shape for l in range(nl)]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        saved = ctx.saved_tensors
+        nl = ctx.nl
+        x, z_cat, coef = saved[0], saved[1], saved[2]
+        ws_ = saved[3:3 + nl]
+        gammas = saved[3 + nl:3 + 2 * nl]
+        dev = x.device
+        P = x.shape[0]
+        dy = dy.contiguous()
+        layers = (L.BnLayer * nl)()
+        grads = (L.BnLayerGrad * nl)()
+        outs: List[Optional[torch.Tensor]] = []
+        for l in range(nl):
+            w = ws_[l]
+            layers[l] = L.BnLayer(_p(w), _p(gammas[l]), _p(gammas[l]), _p(gammas[l]), _p(gammas[l]),
+                                  _p(gammas[l]), None, w.shape[1], w.shape[0])
+            dw = torch.empty_like(w)
+            db = torch.empty(w.shape[0], dtype=torch.float32, device=dev)
+            dg = torch.empty_like(db)
+            dbt = torch.empty_like(db)
+            grads[l] = L.BnLayerGrad(_p(dw), _p(db), _p(dg), _p(dbt))
+            outs += [dw.reshape(ctx.wshapes[l]), db, dg, dbt]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        nb = L.lib().prh_mlp_stack_workspace_bytes(P, nl, layers)
+        ws = _ws(dev, nb)
+        L.check(L.lib().prh_mlp_stack_backward(layers, nl, ctx.relu_last, _p(x), P, ctx.training,
+                                               _p(dy), _p(z_cat), _p(coef[0]), _p(coef[1]),
+                                               _p(coef[2]), _p(coef[3]), grads, _p(dx), _p(ws),
+                                               ws.numel(), dev.index, _stream(dev)),
+                "prh_mlp_stack_backward")
+        return (dx, None, None, None, None, None, *outs)
+
+
+def mlp_stack(x, layers: Sequence[Sequence[torch.Tensor]], buffers: Sequence[torch.Tensor],
+              relu_last: bool, training: bool, momentum: float, eps: float):
+    flat = [t for ly in layers for t in ly]
+    return MlpStackFn.apply(x, relu_last, training, momentum, eps, list(buffers), *flat)
+
+
+# ------------------------------------------------------------------------------------------
+# MultiScalePointNetEncoder
+# ------------------------------------------------------------------------------------------
+ENC_PARAM_ORDER = (
+    [f"conv{k}.{n}" for k in range(1, 6) for n in ("weight", "bias")]
+    + [f"bn{k}.{n}" for k in range(1, 6) for n in ("weight", "bias")]
+    + ["fusion.0.weight", "fusion.0.bias", "fusion.1.weight", "fusion.1.bias",
+       "intensity_gate.0.weight", "intensity_gate.0.bias", "intensity_gate.2.weight",
+       "intensity_gate.2.bias"])
+
+
+def _enc_params_struct(params, buffers, C_in):
+    """params in ENC_PARAM_ORDER (conv weights already 2-D contiguous); buffers =
+    [rm, rv, nbt] * 6 (bn1..5, fusion.1) or None (backward: statistics not touched)."""
+    prm = L.EncoderParams()
+    prm.in_channel = C_in
+    out_dim = params[8].shape[0]
+    prm.out_dim = out_dim
+    for k in range(5):
+        w, b = params[2 * k], params[2 * k + 1]
+        g, beta = params[10 + 2 * k], params[11 + 2 * k]
+        if buffers is not None:
+            rm, rv, nbt = buffers[3 * k], buffers[3 * k + 1], buffers[3 * k + 2]
+        else:
+            rm, rv, nbt = g, g, None
+        prm.conv[k] = _bn_layer(w, b, g, beta, rm, rv, nbt)
+    if buffers is not None:
+        rm, rv, nbt = buffers[15], buffers[16], buffers[17]
+    else:
+        rm, rv, nbt = params[22], params[22], None
+    prm.fusion = _bn_layer(params[20], params[21], params[22], params[23], rm, rv, nbt)
+    prm.gate_w1, prm.gate_b1 = _p(params[24]), _p(params[25])
+    prm.gate_w2, prm.gate_b2 = _p(params[26]), _p(params[27])
+    return prm
+
+
+class EncoderFn(torch.autograd.Function):
+    """MultiScalePointNetEncoder.forward (src/model.py:39-62) on point-major input.
+    x (B,N,C) -> (gfeat (B,2*out) or None, fused (B,N,out))."""
+
+    @staticmethod
+    def forward(ctx, x, want_global, training, momentum, eps, buffers, *params):
+        _req_gpu_f32(x, "input")
+        dev = x.device
+        x = x.contiguous()
+        B, N, Cin = x.shape
+        p2 = list(params)
+        for i in (0, 2, 4, 6, 8, 20, 24, 26):    # Conv1d weights (cout,cin,1) -> (cout,cin)
+            p2[i] = params[i].reshape(params[i].shape[0], -1).contiguous()
+        for t in p2:
+            _req_gpu_f32(t, "parameter")
+        if Cin != p2[0].shape[1]:
+            raise RuntimeError(f"Given groups=1, weight of size {list(params[0].shape)}, expected input"
+                               f"[{B}, {Cin}, {N}] to have {p2[0].shape[1]} channels, but got {Cin} channels instead")
+        if training and B * N < 2:
+            raise ValueError(f"Expected more than 1 value per channel when training, got input size {(B, Cin, N)}")
+        out_dim = p2[8].shape[0]
+        cat = 64 + 128 + 256 + 512 + out_dim
+        P = B * N
+        need_bwd = torch.is_grad_enabled() and (x.requires_grad or any(t.requires_grad for t in params))
+        z_cat = torch.empty((P, cat), dtype=torch.float32, device=dev)
+        z_fus = torch.empty((P, out_dim), dtype=torch.float32, device=dev)
+        gate = torch.empty((P, out_dim), dtype=torch.float32, device=dev) if need_bwd else None
+        coef = torch.empty((4, cat + out_dim), dtype=torch.float32, device=dev)
+        fused = torch.empty((B, N, out_dim), dtype=torch.float32, device=dev)
+        gfeat = torch.empty((B, 2 * out_dim), dtype=torch.float32, device=dev) if want_global else None
+        argmax = torch.empty((B, out_dim), dtype=torch.int32, device=dev) if (want_global and need_bwd) else None
+        prm = _enc_params_struct(p2, buffers, Cin)
+        sv = L.EncoderSaved(_p(z_cat), _p(z_fus), _p(gate), _p(coef[0]), _p(coef[1]), _p(coef[2]),
+                            _p(coef[3]), _p(argmax))
+        nb = L.lib().prh_encoder_workspace_bytes(B, N, Cin, out_dim, 0)
+        ws = _ws(dev, nb)
+        L.check(L.lib().prh_encoder_forward(C.byref(prm), _p(x), B, N, int(training), float(momentum),
+                                            float(eps), _p(fused), _p(gfeat), C.byref(sv), _p(ws),
+                                            ws.numel(), dev.index, _stream(dev)),
+                "prh_encoder_forward")
+        if need_bwd:
+            ctx.save_for_backward(x, z_cat, z_fus, gate, coef, argmax if argmax is not None else coef, *p2)
+            ctx.has_argmax = argmax is not None
+            ctx.training = int(training)
+            ctx.pshapes = [t.shape for t in params]
+            ctx.consumed = False
+        if want_global:
+            return gfeat, fused
+        return None, fused
+
+    @staticmethod
+    def backward(ctx, d_gfeat, d_fused):
+        if ctx.consumed:
+            raise RuntimeError("pointnet_refine_amd encoder: backward through the same graph a second "
+                               "time is not supported (saved activations are consumed in place)")
+        ctx.consumed = True
+        saved = ctx.saved_tensors
+        x, z_cat, z_fus, gate, coef, argmax = saved[:6]
+        p2 = list(saved[6:])
+        dev = x.device
+        B, N, Cin = x.shape
+        out_dim = p2[8].shape[0]
+        if d_fused is None:
+            d_fused = torch.zeros((B, N, out_dim), dtype=torch.float32, device=dev)
+        else:
+            d_fused = d_fused.contiguous().clone() if d_fused.is_contiguous() else d_fused.contiguous()
+        if d_gfeat is not None:
+            if not ctx.has_argmax:
+                raise RuntimeError("encoder backward: gradient for global_feat but no argmax saved")
+            d_gfeat = d_gfeat.contiguous()
+        prm = _enc_params_struct(p2, None, Cin)
+        sv = L.EncoderSaved(_p(z_cat), _p(z_fus), _p(gate), _p(coef[0]), _p(coef[1]), _p(coef[2]),
+                            _p(coef[3]), _p(argmax) if ctx.has_argmax else None)
+        g = [torch.empty_like(t) for t in p2]
+        gr = L.EncoderGrads()
+        for k in range(5):
+            gr.conv[k] = L.BnLayerGrad(_p(g[2 * k]), _p(g[2 * k + 1]), _p(g[10 + 2 * k]), _p(g[11 + 2 * k]))
+        gr.fusion = L.BnLayerGrad(_p(g[20]), _p(g[21]), _p(g[22]), _p(g[23]))
+        gr.d_gate_w1, gr.d_gate_b1, gr.d_gate_w2, gr.d_gate_b2 = _p(g[24]), _p(g[25]), _p(g[26]), _p(g[27])
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        nb = L.lib().prh_encoder_workspace_bytes(B, N, Cin, out_dim, 1)
+        ws = _ws(dev, nb)
+        L.check(L.lib().prh_encoder_backward(C.byref(prm), _p(x), B, N, ctx.training, _p(d_fused),
+                                             _p(d_gfeat), C.byref(sv), C.byref(gr), _p(dx), _p(ws),
+                                             ws.numel(), dev.index, _stream(dev)),
+                "prh_encoder_backward")
+        grads = [gi.reshape(s) for gi, s in zip(g, ctx.pshapes)]
+        return (dx, None, None, None, None, None, *grads)
+
+
+def encoder(x_pm, params, buffers, want_global: bool, training: bool, momentum: float, eps: float):
+    return EncoderFn.apply(x_pm, want_global, training, momentum, eps, list(buffers), *params)

@@ -1,0 +1,151 @@
+"""HIP encoder / linear / point_mlp (through the nn.Module surface -> C ABI) against the
+oracle on the same seeded inputs and against the golden vectors.
+
+Tolerances: forward max-abs <= 1e-4 (north_star); gradients rel-L2 <= 5e-3 per tensor
+with median <= 1e-3 (ReLU/max mask flips inside fp32 noise make max-abs on gradients
+meaningless, see oracle/make_golden.py); BN running statistics rel 1e-5.
+"""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import maxdiff, rel_l2
+from oracle import linerefine_oracle as O
+from oracle import procedural as P
+
+pytestmark = pytest.mark.gpu
+
+
+def _pre_bn_bias(k):
+    return bool(re.search(r"(conv\d\.bias|fusion\.0\.bias|point_mlp\.[036]\.bias)$", k))
+
+
+def _encoder(C, sd):
+    from pointnet_refine_amd.model import MultiScalePointNetEncoder
+    m = MultiScalePointNetEncoder(in_channel=C, out_dim=1024)
+    m.load_state_dict(sd, strict=True)
+    return m.cuda()
+
+
+@pytest.mark.parametrize("name,C,B,N", [("g3_encoder_c4_train", 4, 4, 192), ("g4_encoder_c6_train", 6, 3, 160)])
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_encoder_vs_oracle_and_golden(golden_dir, name, C, B, N, mode):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    sd = P.encoder_state_dict(C, 1024, seed=3)
+    sd["fusion.1.weight"][5] = 0.0     # dead channel: max-pool tie -> first index
+    sd["fusion.1.bias"][5] = -1.0
+    ctx, _, _ = P.synth_batch(B, N, C, 32, seed=77)
+    r = np.random.default_rng(5)
+    up_g = torch.from_numpy(r.normal(0, 1, (B, 2048)).astype(np.float32))
+    up_f = torch.from_numpy(r.normal(0, 1, (B, N, 1024)).astype(np.float32))
+
+    m = _encoder(C, sd)
+    m.train(mode == "train")
+    x = ctx.cuda().requires_grad_(True)
+    gf, fu_cm = m(x.transpose(2, 1))                 # reference contract: (B,C,N) in, (B,out,N) out
+    assert fu_cm.shape == (B, 1024, N) and gf.shape == (B, 2048)
+    ((gf * up_g.cuda()).sum() + (fu_cm.transpose(2, 1) * up_f.cuda()).sum()).backward()
+
+    p = O.as_params(sd, requires_grad=True)
+    ox = ctx.clone().requires_grad_(True)
+    ns = {}
+    o_g, o_f = O.encoder_forward(p, ox, "", mode == "train", ns)
+    ((o_g * up_g).sum() + (o_f * up_f).sum()).backward()
+
+    # forward: oracle and golden
+    assert maxdiff(gf, o_g) < 1e-4 and maxdiff(fu_cm.transpose(2, 1), o_f) < 1e-4
+    assert maxdiff(gf, g[f"{mode}::gfeat"]) < 1e-4
+    assert maxdiff(fu_cm.transpose(2, 1)[:, ::8, ::16], g[f"{mode}::fused_sub"]) < 1e-4
+    # input gradient
+    assert rel_l2(ox.grad, x.grad) < 5e-3
+    assert rel_l2(g[f"{mode}::dx"], x.grad) < 5e-3
+    # parameter gradients
+    rels = {}
+    named = dict(m.named_parameters())
+    for k, nrm in zip(g[f"{mode}::grad_keys"], g[f"{mode}::grad_norms"]):
+        k = str(k)
+        if mode == "train" and _pre_bn_bias(k):
+            assert float(named[k].grad.abs().max()) < 1e-3     # analytically zero
+            continue
+        rels[k] = rel_l2(p[k].grad.reshape(named[k].shape), named[k].grad)
+        assert abs(float(named[k].grad.double().norm()) - nrm) <= 5e-3 * nrm + 1e-9, k
+        assert rel_l2(g[f"{mode}::gh::{k}"], named[k].grad.reshape(-1)[:64]) < 2e-2, k
+    assert max(rels.values()) < 5e-3, max(rels, key=rels.get)
+    assert float(np.median(list(rels.values()))) < 1e-3
+    # running statistics
+    msd = m.state_dict()
+    if mode == "train":
+        for k, v in ns.items():
+            assert maxdiff(msd[k], v) <= 1e-5 * float(v.double().abs().max()) + 1e-6, k
+            assert maxdiff(msd[k], g["st::" + k]) <= 1e-5 * float(v.double().abs().max()) + 1e-6, k
+    else:
+        for k, v in sd.items():
+            if "running" in k or "num_batches" in k:
+                assert torch.equal(msd[k].cpu(), v), k
+
+
+def test_encoder_backward_twice_raises():
+    sd = P.encoder_state_dict(4, 1024, seed=3)
+    m = _encoder(4, sd).train()
+    ctx, _, _ = P.synth_batch(2, 64, 4, 32, seed=1)
+    gf, fu = m(ctx.cuda().transpose(2, 1))
+    loss = fu.sum() + gf.sum()
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second"):
+        loss.backward()
+
+
+def test_encoder_channel_mismatch_raises():
+    m = _encoder(4, P.encoder_state_dict(4, 1024, seed=3)).eval()
+    with pytest.raises(RuntimeError, match="channels"):
+        m(torch.randn(2, 3, 64, device="cuda"))
+    with pytest.raises(ValueError, match="more than 1 value"):
+        m.train()(torch.randn(1, 4, 1, device="cuda"))
+
+
+@pytest.mark.parametrize("B,N", [(1, 1), (3, 7), (2, 129), (5, 1000)])
+def test_encoder_ragged_sizes_eval(B, N):
+    sd = P.encoder_state_dict(4, 1024, seed=3)
+    m = _encoder(4, sd).eval()
+    ctx, _, _ = P.synth_batch(B, N, 4, 32, seed=B * 100 + N)
+    with torch.no_grad():
+        gf, fu = m(ctx.cuda().transpose(2, 1))
+        o_g, o_f = O.encoder_forward(O.as_params(sd), ctx, "", False)
+    assert maxdiff(gf, o_g) < 1e-4 and maxdiff(fu.transpose(2, 1), o_f) < 1e-4
+
+
+def test_point_mlp_c3_golden(golden_dir):
+    from pointnet_refine_amd.model import LineRefineNet
+    g = np.load(os.path.join(golden_dir, "g5_point_mlp_c3.npz"))
+    sd = P.linerefine_state_dict(0)
+    m = LineRefineNet()
+    m.load_state_dict(sd, strict=True)
+    m.cuda()
+    r = np.random.default_rng(9)
+    x = torch.from_numpy(r.normal(0, 1.5, (4, 1024, 3)).astype(np.float32))
+    for mode in ("train", "eval"):
+        m.load_state_dict(sd, strict=True)
+        m.train(mode == "train")
+        with torch.no_grad():
+            y = m.encode_line(x.cuda())
+        assert maxdiff(y[:, ::16, ::2], g[mode]) < 1e-4
+
+
+def test_linear_fwd_bwd():
+    from pointnet_refine_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(5, 77, 1024, generator=g)
+    w = torch.randn(256, 1024, generator=g) / 32
+    b = torch.randn(256, generator=g)
+    up = torch.randn(5, 77, 256, generator=g)
+    xs = [t.clone().requires_grad_(True) for t in (x, w, b)]
+    (torch.nn.functional.linear(*[t.double() for t in xs]) * up.double()).sum().backward()
+    ys = [t.cuda().requires_grad_(True) for t in (x, w, b)]
+    out = ops.linear(*ys)
+    (out * up.cuda()).sum().backward()
+    assert maxdiff(out, torch.nn.functional.linear(x.double(), w.double(), b.double())) < 1e-4
+    for a, bb in zip(xs, ys):
+        assert rel_l2(a.grad, bb.grad) < 1e-5

@@ -1,0 +1,61 @@
+"""Raw GEMM cores through the C ABI against fp64 torch on ragged shapes."""
+import ctypes as C
+
+import pytest
+import torch
+
+from conftest import maxdiff
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from pointnet_refine_amd import _lib
+    return _lib.lib()
+
+
+@pytest.mark.parametrize("m,n,k", [(128, 128, 32), (1, 4, 4), (257, 64, 64), (1000, 1984, 1024),
+                                   (333, 100, 1984), (4096, 1024, 1984), (70, 3, 128)])
+def test_gemm_nt(lib, m, n, k):
+    g = torch.Generator(device="cuda").manual_seed(m * 7 + n * 3 + k)
+    a = torch.randn(m, k, device="cuda", generator=g)
+    w = torch.randn(n, k, device="cuda", generator=g)
+    # asymmetric structure so a transposed C would be caught
+    a[:, 0] += torch.arange(m, device="cuda") * 0.01
+    c = torch.full((m, n), float("nan"), device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = lib.prh_test_gemm_nt(_p(a), _p(w), _p(c), m, n, k, 0, st)
+    assert rc == 0, lib.prh_last_error()
+    ref = a.double() @ w.double().t()
+    tol = 2e-6 * k ** 0.5 * float(ref.abs().max() / k ** 0.5 + 1)
+    assert maxdiff(c, ref) < max(tol, 1e-5) * 4
+
+
+@pytest.mark.parametrize("p,mo,ni", [(32, 128, 128), (1, 4, 4), (1000, 64, 4), (5000, 1024, 1984),
+                                     (100000, 128, 64), (777, 256, 1024), (65, 1024, 64)])
+def test_gemm_tn(lib, p, mo, ni):
+    g = torch.Generator(device="cuda").manual_seed(p + mo + ni)
+    a = torch.randn(p, mo, device="cuda", generator=g)
+    b = torch.randn(p, ni, device="cuda", generator=g)
+    c = torch.full((mo, ni), float("nan"), device="cuda")
+    cs = torch.full((mo,), float("nan"), device="cuda")
+    nb = lib.prh_test_gemm_tn_workspace_bytes(p, mo, ni)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = lib.prh_test_gemm_tn(_p(a), _p(b), _p(c), _p(cs), p, mo, ni, _p(ws), nb, 0, st)
+    assert rc == 0, lib.prh_last_error()
+    ref = a.double().t() @ b.double()
+    assert maxdiff(c, ref) < 1e-5 * p ** 0.5 * 4
+    assert maxdiff(cs, a.double().sum(0)) < 1e-5 * p ** 0.5 * 4
+
+
+def test_gemm_rejects_unaligned_k(lib):
+    a = torch.randn(8, 6, device="cuda")
+    c = torch.empty(8, 8, device="cuda")
+    rc = lib.prh_test_gemm_nt(_p(a), _p(a), _p(c), 8, 8, 6, 0, C.c_void_p(0))
+    assert rc == -1 and b"multiples of 4" in lib.prh_last_error()

