@@ -248,7 +248,7 @@ class EncoderFn(torch.autograd.Function):
         out_dim = p2[8].shape[0]
         cat = 64 + 128 + 256 + 512 + out_dim
         P = B * N
-        need_bwd = torch.is_grad_enabled() and (x.requires_grad or any(t.requires_grad for t in params))
+        need_bwd = any(ctx.needs_input_grad)
         z_cat = torch.empty((P, cat), dtype=torch.float32, device=dev)
         z_fus = torch.empty((P, out_dim), dtype=torch.float32, device=dev)
         gate = torch.empty((P, out_dim), dtype=torch.float32, device=dev) if need_bwd else None
