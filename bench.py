@@ -1,0 +1,172 @@
+#!/usr/bin/env python
+"""Benchmark of the LineRefineNet hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N=1: plain process)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One STEP = one training pass over one synthetic batch per GPU, exactly what
+train_dist.py:173-189 does per iteration: zero_grad, forward, deep-supervision L1 loss,
+backward (DDP gradient all-reduce over RCCL when N>1), Adam step.  fp32 throughout (the
+reference's dtype; the 1e-4 parity gate applies to this path).  Inputs are generated on the
+device before the timed region.  Weak scaling: every rank processes --batch segments.
+
+Prints ONE JSON line on rank 0 (contract in the task brief) with two extra objects:
+  roofline      the dominant kernel of the timed region, timed live with HIP events on its
+                launch stream (library profiler), against the fp32 MFMA peak
+  cpu_baseline  the oracle (CPU restatement of the reference, kind "port") timed on the
+                host cores on a bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4096, help="segments per GPU per step")
+    ap.add_argument("--points", type=int, default=1024, help="context points per segment")
+    ap.add_argument("--decoder-chunk", type=int, default=512,
+                    help="segments per decoder micro-batch (bounds the stock-PyTorch decoder's "
+                         "activation memory; results are identical to the unchunked step)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=16)
+    return ap.parse_args()
+
+
+def l1_deep_supervision(out, target):
+    """train_dist.py:180-186: mean over the 6 layers of nn.L1Loss(pred_l, target)."""
+    return (out - target.unsqueeze(0)).abs().mean()
+
+
+def cpu_baseline(points, batch):
+    """Oracle (port of the reference) fwd+bwd on the host cores: bounded sample."""
+    from oracle import linerefine_oracle as O
+    from oracle import procedural as P
+    torch.set_num_threads(os.cpu_count() or 1)
+    sd = P.linerefine_state_dict(0)
+    ctx, noisy, target = P.synth_batch(batch, points, 4, 32, seed=1234)
+    best = float("inf")
+    for it in range(3):
+        p = O.as_params(sd, requires_grad=True)
+        t0 = time.perf_counter()
+        out = O.linerefine_forward(p, ctx, noisy, training=True, new_stats={})
+        O.deep_supervision_l1(out, target).backward()
+        dt = time.perf_counter() - t0
+        if it > 0:
+            best = min(best, dt)
+    return {"value": round(batch / best, 3), "unit": "segments/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"oracle/linerefine_oracle.py fwd+bwd (no optimizer), B={batch}, N={points}, fp32, "
+                      f"torch-CPU {torch.get_num_threads()} threads, 1 warm-up + best of 2"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")     # RCCL on ROCm
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from pointnet_refine_amd import _lib
+    from pointnet_refine_amd.model import LineRefineNet
+    from pointnet_refine_amd.synth import synthetic_batch
+    from pointnet_refine_amd.train_step import TrainStep
+    lib = _lib.lib()
+
+    torch.manual_seed(0)
+    model = LineRefineNet().to(dev).train()
+    if world > 1:
+        for p in model.parameters():                 # same start on every rank (DDP does this)
+            dist.broadcast(p.data, 0)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    step = TrainStep(model, opt, decoder_chunk=args.decoder_chunk, world_size=world)
+
+    B, N = args.batch, args.points
+    ctx, noisy, target = synthetic_batch(B, N, dev, seed=1234 + rank)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        loss = step(ctx, noisy, target)
+    sync()
+    lib.prh_profile_enable(4096)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(ctx, noisy, target)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-kernel live durations (HIP events on the launch stream)
+    agg = {}
+    name = C.create_string_buffer(64)
+    ms, fl, by = C.c_float(), C.c_double(), C.c_double()
+    for i in range(lib.prh_profile_count()):
+        lib.prh_profile_read(i, name, 64, C.byref(ms), C.byref(fl), C.byref(by))
+        a = agg.setdefault(name.value.decode(), [0, 0.0, fl.value, by.value])
+        a[0] += 1
+        a[1] += ms.value
+    lib.prh_profile_enable(0)
+    hip_ms = sum(a[1] for a in agg.values())
+    dom = max(agg.items(), key=lambda kv: kv[1][1])
+    dname, (cnt, tot_ms, flops, bytes_) = dom
+    avg_ms = tot_ms / cnt
+    achieved = flops / (avg_ms * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "kernel": dname, "achieved": round(achieved, 2),
+                "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": cnt,
+                "algorithmic_gbs": round(bytes_ / (avg_ms * 1e-3) / 1e9, 1),
+                "hbm_frac": round(bytes_ / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "hip_gemm_ms_per_step": round(hip_ms / args.steps, 2)}
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        line = {
+            "metric": "lane segments/sec (fwd+bwd) at B=4096,N=1024; HBM GB/s vs roofline",
+            "value": round(world * B * args.steps / dt, 2), "unit": "segments/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"LineRefineNet training step (fwd + deep-supervision L1 + bwd + Adam), "
+                                   f"B={B}/GPU, N={N}, M=32, C=4, fp32",
+                       "global_batch": world * B, "points": N,
+                       "parallelism": f"dp{world}" + (" (RCCL gradient all-reduce)" if world > 1 else ""),
+                       "decoder_chunk": args.decoder_chunk},
+            "loss": round(float(loss), 6),
+            "max_mem_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(N, args.cpu_batch)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

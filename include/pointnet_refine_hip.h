@@ -147,6 +147,14 @@ size_t prh_test_gemm_tn_workspace_bytes(int p, int mo, int ni);
 int prh_test_gemm_tn(const float* a, const float* b, float* c, float* colsum, int p, int mo,
                      int ni, void* workspace, size_t workspace_bytes, int device, void* stream);
 
+/* Optional launch profiler used by bench.py: when enabled (capacity > 0) every GEMM launch is
+ * bracketed by HIP events on the launch stream; prh_profile_read returns its duration and
+ * the algorithmic FLOPs / bytes of that launch.  capacity 0 disables and frees the events. */
+int prh_profile_enable(int capacity);
+int prh_profile_count(void);
+int prh_profile_reset(void);
+int prh_profile_read(int i, char* name, int name_len, float* ms, double* flops, double* bytes);
+
 const char* prh_last_error(void);
 const char* prh_version(void);
 

@@ -52,6 +52,7 @@ EXPORTS = [
     "prh_linear_forward", "prh_linear_backward_workspace_bytes", "prh_linear_backward",
     "prh_mlp_stack_workspace_bytes", "prh_mlp_stack_forward", "prh_mlp_stack_backward",
     "prh_test_gemm_nt", "prh_test_gemm_tn_workspace_bytes", "prh_test_gemm_tn",
+    "prh_profile_enable", "prh_profile_count", "prh_profile_reset", "prh_profile_read",
     "prh_last_error", "prh_version",
 ]
 
@@ -106,6 +107,13 @@ def _bind(lib):
     lib.prh_mlp_stack_backward.restype = i
     lib.prh_mlp_stack_backward.argtypes = [C.POINTER(BnLayer), i, i, vp, i, i, vp, vp, vp, vp, vp,
                                            vp, C.POINTER(BnLayerGrad), vp, vp, sz, i, vp]
+    lib.prh_profile_enable.restype = i
+    lib.prh_profile_enable.argtypes = [i]
+    lib.prh_profile_count.restype = i
+    lib.prh_profile_reset.restype = i
+    lib.prh_profile_read.restype = i
+    lib.prh_profile_read.argtypes = [i, C.c_char_p, i, C.POINTER(C.c_float), C.POINTER(C.c_double),
+                                     C.POINTER(C.c_double)]
     lib.prh_test_gemm_nt.restype = i
     lib.prh_test_gemm_nt.argtypes = [vp, vp, vp, i, i, i, i, vp]
     lib.prh_test_gemm_tn_workspace_bytes.restype = sz

@@ -9,6 +9,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
+#include <vector>
+
 #include "prh_gemm.hpp"
 #include "prh_kernels.hpp"
 
@@ -35,6 +38,32 @@ int fail(int code, const char* fmt, ...) {
   } while (0)
 
 #define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
+
+// ------------------------------------------------------------------ optional profiler
+// bench.py brackets every GEMM launch with HIP events ON THE LAUNCH STREAM so it can quote
+// the dominant kernel's live duration next to its algorithmic FLOPs/bytes (roofline object
+// of the bench line).  Off by default; the entry points stay stateless when it is off.
+struct ProfRec { hipEvent_t e0, e1; char name[64]; double flops, bytes; };
+struct Profiler {
+  std::mutex mu;
+  std::vector<ProfRec> recs;
+  size_t used = 0;
+  bool on = false;
+} g_prof;
+
+struct ProfScope {
+  ProfRec* r = nullptr; hipStream_t st;
+  ProfScope(const char* name, double flops, double bytes, hipStream_t s) : st(s) {
+    if (!g_prof.on) return;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    if (g_prof.used >= g_prof.recs.size()) return;
+    r = &g_prof.recs[g_prof.used++];
+    snprintf(r->name, sizeof(r->name), "%s", name);
+    r->flops = flops; r->bytes = bytes;
+    (void)hipEventRecord(r->e0, st);
+  }
+  ~ProfScope() { if (r) (void)hipEventRecord(r->e1, st); }
+};
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
@@ -68,6 +97,13 @@ int launch_nt(NTParams p, hipStream_t st) {
                 p.K, p.lda, p.ldw);
   p.tiles_n = cdiv(p.N, BN);
   const long tiles = (long)p.tiles_n * cdiv(p.M, BM);
+  char nm[64];
+  snprintf(nm, sizeof(nm), "gemm_nt<%d,%d> K=%d N=%d", PRO, EPI, p.K, p.N);
+  // algorithmic traffic: A (+A2) read once, C written once (+E1/C_old reads), W read once
+  const double by = 4.0 * ((double)p.M * p.K * (PRO == PRO_BNBWD ? 2 : (PRO == PRO_GATE1 ? 0 : 1)) +
+                           (double)p.M * p.N * (EPI == EPI_GATE ? 3 : (EPI == EPI_DGRAD ? 2 : 1)) +
+                           (double)p.N * p.K);
+  ProfScope ps(nm, 2.0 * p.M * (double)p.N * p.K, by, st);
   hipLaunchKernelGGL((gemm_nt_kernel<PRO, EPI>), dim3((unsigned)tiles), dim3(256), 0, st, p);
   LAUNCH_CHECK();
   return PRH_OK;
@@ -113,7 +149,14 @@ int launch_tn(TNParams p, float* slab, float* colsum_slab, float* C, long ldc, f
   p.slab = slab;
   p.colsum = colsum_out != nullptr ? colsum_slab : nullptr;
   const long blocks = (long)pl.tiles_m * pl.tiles_n * pl.splits;
-  hipLaunchKernelGGL((gemm_tn_kernel<PROA, PROB>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+  {
+    char nm[64];
+    snprintf(nm, sizeof(nm), "gemm_tn<%d,%d> Mo=%d Ni=%d", PROA, PROB, p.Mo, p.Ni);
+    const double by = 4.0 * ((double)p.P * p.Mo * (PROA == PRO_BNBWD ? 2 : 1) +
+                             (double)p.P * (PROB == PRO_GATE1 ? 1 : p.Ni) + (double)p.Mo * p.Ni);
+    ProfScope ps(nm, 2.0 * p.P * (double)p.Mo * p.Ni, by, st);
+    hipLaunchKernelGGL((gemm_tn_kernel<PROA, PROB>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+  }
   LAUNCH_CHECK();
   if (C != nullptr) {
     const size_t len = (size_t)p.Mo * p.Ni;
@@ -692,6 +735,42 @@ int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B,
       LAUNCH_CHECK();
     }
   }
+  return PRH_OK;
+}
+
+// ------------------------------------------------------------------ profiler
+int prh_profile_enable(int capacity) {
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  for (auto& r : g_prof.recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  g_prof.recs.clear();
+  g_prof.used = 0;
+  g_prof.on = false;
+  if (capacity <= 0) return PRH_OK;
+  g_prof.recs.resize((size_t)capacity);
+  for (auto& r : g_prof.recs) {
+    HIP_TRY(hipEventCreate(&r.e0));
+    HIP_TRY(hipEventCreate(&r.e1));
+  }
+  g_prof.on = true;
+  return PRH_OK;
+}
+int prh_profile_count(void) {
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  return (int)g_prof.used;
+}
+int prh_profile_reset(void) {
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  g_prof.used = 0;
+  return PRH_OK;
+}
+int prh_profile_read(int i, char* name, int name_len, float* ms, double* flops, double* bytes) {
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  if (i < 0 || (size_t)i >= g_prof.used) return fail(PRH_ERR_ARG, "profile_read: index %d out of range", i);
+  ProfRec& r = g_prof.recs[(size_t)i];
+  HIP_TRY(hipEventSynchronize(r.e1));
+  HIP_TRY(hipEventElapsedTime(ms, r.e0, r.e1));
+  snprintf(name, (size_t)name_len, "%s", r.name);
+  *flops = r.flops; *bytes = r.bytes;
   return PRH_OK;
 }
 

@@ -177,12 +177,10 @@ class LineRefineNet(nn.Module):
                           training=self.training, momentum=pm[1].momentum, eps=pm[1].eps)
         return y.reshape(B, M, -1)
 
-    def forward(self, context, noisy_line):
-        if context.dim() != 3 or noisy_line.dim() != 3:
-            raise RuntimeError("LineRefineNet expects context (B,N,4) and noisy_line (B,M,3)")
-        memory = self.encode_context(context)                       # (B, N, 256)
+    def decode(self, context, noisy_line, memory, tgt):
+        """Iterative refinement (src/model.py:197-234) given memory (B,N,256) and the initial
+        queries tgt (B,M,256).  No BatchNorm in here, so it may be run on batch chunks."""
         pos_mem = self.pos_emb(context[:, :, :3])                   # (B, N, 256)
-        tgt = self.encode_line(noisy_line)                          # (B, M, 256)
         current_line_coords = noisy_line.clone()
         all_pred_offsets = []
         for decoder_layer, reg_branch in zip(self.decoder_layers, self.reg_branches):
@@ -192,3 +190,10 @@ class LineRefineNet(nn.Module):
             current_line_coords = current_line_coords + delta_offset      # no detach (H5)
             all_pred_offsets.append(current_line_coords - noisy_line)
         return torch.stack(all_pred_offsets)
+
+    def forward(self, context, noisy_line):
+        if context.dim() != 3 or noisy_line.dim() != 3:
+            raise RuntimeError("LineRefineNet expects context (B,N,4) and noisy_line (B,M,3)")
+        memory = self.encode_context(context)                       # (B, N, 256)
+        tgt = self.encode_line(noisy_line)                          # (B, M, 256)
+        return self.decode(context, noisy_line, memory, tgt)
