@@ -53,11 +53,28 @@ def l1_deep_supervision(out, target):
     return (out - target.unsqueeze(0)).abs().mean()
 
 
+def host_cores():
+    """CPU share of this process: cgroup quota if set, else affinity, capped at 16 (the
+    GPU box hands one GPU 16 cores; os.cpu_count() reports the whole host)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
 def cpu_baseline(points, batch):
     """Oracle (port of the reference) fwd+bwd on the host cores: bounded sample."""
     from oracle import linerefine_oracle as O
     from oracle import procedural as P
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(host_cores())
     sd = P.linerefine_state_dict(0)
     ctx, noisy, target = P.synth_batch(batch, points, 4, 32, seed=1234)
     best = float("inf")
@@ -67,6 +84,7 @@ def cpu_baseline(points, batch):
         out = O.linerefine_forward(p, ctx, noisy, training=True, new_stats={})
         O.deep_supervision_l1(out, target).backward()
         dt = time.perf_counter() - t0
+        log(f"cpu_baseline iter {it}: {dt:.2f} s on {torch.get_num_threads()} threads")
         if it > 0:
             best = min(best, dt)
     return {"value": round(batch / best, 3), "unit": "segments/s", "cores": torch.get_num_threads(),
@@ -108,8 +126,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         loss = step(ctx, noisy, target)
+        if rank == 0:
+            torch.cuda.synchronize(dev)
+            log(f"warmup {i} done, loss {float(loss):.5f}, mem {torch.cuda.max_memory_allocated(dev) / 2**30:.1f} GiB")
     sync()
     lib.prh_profile_enable(4096)
     t0 = time.perf_counter()
@@ -117,6 +138,8 @@ def main():
         loss = step(ctx, noisy, target)
     sync()
     dt = time.perf_counter() - t0
+    if rank == 0:
+        log(f"timed {args.steps} steps in {dt:.3f} s")
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
