@@ -112,9 +112,12 @@ int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B,
 
 /* nn.Linear forward y = act(x W^T + b): context_proj (src/model.py:147,194) and any
  * other Linear on the path.  x [rows,k] (ld ldx), w [n,k], y [rows,n]; relu: 0/1.
- * k and ldx must be multiples of 4. */
+ * k and ldx must be multiples of 4.  workspace (may be NULL: exact fp32 MFMA core only) holds the
+ * split-bf16 weight image of the large-GEMM core. */
+size_t prh_linear_forward_workspace_bytes(int rows, int k, int n);
 int prh_linear_forward(const float* x, long ldx, const float* w, const float* b, float* y,
-                       int rows, int k, int n, int relu, int device, void* stream);
+                       int rows, int k, int n, int relu, void* workspace, size_t workspace_bytes,
+                       int device, void* stream);
 
 /* nn.Linear backward: dx = dy W (NULL = skip), dw = dy^T x, db = colsum(dy).
  * n and k multiples of 4. */
@@ -139,10 +142,19 @@ int prh_mlp_stack_backward(const prh_bn_layer* layers, int n_layers, int relu_la
                            const prh_bn_layer_grad* grads, float* dx, void* workspace,
                            size_t workspace_bytes, int device, void* stream);
 
+/* GEMM core selection: environment PRH_GEMM=fp32 forces the exact fp32 MFMA cores
+ * (v_mfma_f32_32x32x2_f32) everywhere; the default routes large GEMMs to the split-bf16
+ * cores (three bf16 planes per fp32 operand, six v_mfma_f32_32x32x16_bf16 products,
+ * fp32-level error).  Both are checked against the oracle at the same 1e-4 gate.
+ * prh_set_gemm_mode(0 = fp32, 1 = split) overrides the environment at run time
+ * (process-wide; set it before launching work, not concurrently with it). */
+int prh_set_gemm_mode(int mode);
+int prh_get_gemm_mode(void);
+
 /* Raw GEMM cores, exported for the unit tests (tests/test_gemm_gpu.py).
  *   nt: c[m,n] = a[m,k] w[n,k]^T     tn: c[mo,ni] = a[p,mo]^T b[p,ni]          */
 int prh_test_gemm_nt(const float* a, const float* w, float* c, int m, int n, int k,
-                     int device, void* stream);
+                     void* workspace, size_t workspace_bytes, int device, void* stream);
 size_t prh_test_gemm_tn_workspace_bytes(int p, int mo, int ni);
 int prh_test_gemm_tn(const float* a, const float* b, float* c, float* colsum, int p, int mo,
                      int ni, void* workspace, size_t workspace_bytes, int device, void* stream);

@@ -14,7 +14,8 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "libpointnet_refine_hip.so")
-_SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("prh_lib.hip", "prh_gemm.hpp", "prh_kernels.hpp")]
+_SOURCES = [os.path.join(_HERE, "csrc", f)
+            for f in ("prh_lib.hip", "prh_gemm.hpp", "prh_gemm_s3.hpp", "prh_kernels.hpp")]
 _HEADER = os.path.join(_ROOT, "include", "pointnet_refine_hip.h")
 
 PRH_MAX_LAYERS = 8
@@ -49,10 +50,12 @@ class EncoderSaved(C.Structure):
 
 EXPORTS = [
     "prh_encoder_workspace_bytes", "prh_encoder_forward", "prh_encoder_backward",
-    "prh_linear_forward", "prh_linear_backward_workspace_bytes", "prh_linear_backward",
+    "prh_linear_forward_workspace_bytes", "prh_linear_forward",
+    "prh_linear_backward_workspace_bytes", "prh_linear_backward",
     "prh_mlp_stack_workspace_bytes", "prh_mlp_stack_forward", "prh_mlp_stack_backward",
     "prh_test_gemm_nt", "prh_test_gemm_tn_workspace_bytes", "prh_test_gemm_tn",
     "prh_profile_enable", "prh_profile_count", "prh_profile_reset", "prh_profile_read",
+    "prh_set_gemm_mode", "prh_get_gemm_mode",
     "prh_last_error", "prh_version",
 ]
 
@@ -94,7 +97,9 @@ def _bind(lib):
                                          C.POINTER(EncoderSaved), C.POINTER(EncoderGrads), vp, vp,
                                          sz, i, vp]
     lib.prh_linear_forward.restype = i
-    lib.prh_linear_forward.argtypes = [vp, lg, vp, vp, vp, i, i, i, i, i, vp]
+    lib.prh_linear_forward.argtypes = [vp, lg, vp, vp, vp, i, i, i, i, vp, sz, i, vp]
+    lib.prh_linear_forward_workspace_bytes.restype = sz
+    lib.prh_linear_forward_workspace_bytes.argtypes = [i, i, i]
     lib.prh_linear_backward_workspace_bytes.restype = sz
     lib.prh_linear_backward_workspace_bytes.argtypes = [i, i, i]
     lib.prh_linear_backward.restype = i
@@ -107,6 +112,9 @@ def _bind(lib):
     lib.prh_mlp_stack_backward.restype = i
     lib.prh_mlp_stack_backward.argtypes = [C.POINTER(BnLayer), i, i, vp, i, i, vp, vp, vp, vp, vp,
                                            vp, C.POINTER(BnLayerGrad), vp, vp, sz, i, vp]
+    lib.prh_set_gemm_mode.restype = i
+    lib.prh_set_gemm_mode.argtypes = [i]
+    lib.prh_get_gemm_mode.restype = i
     lib.prh_profile_enable.restype = i
     lib.prh_profile_enable.argtypes = [i]
     lib.prh_profile_count.restype = i
@@ -115,7 +123,7 @@ def _bind(lib):
     lib.prh_profile_read.argtypes = [i, C.c_char_p, i, C.POINTER(C.c_float), C.POINTER(C.c_double),
                                      C.POINTER(C.c_double)]
     lib.prh_test_gemm_nt.restype = i
-    lib.prh_test_gemm_nt.argtypes = [vp, vp, vp, i, i, i, i, vp]
+    lib.prh_test_gemm_nt.argtypes = [vp, vp, vp, i, i, i, vp, sz, i, vp]
     lib.prh_test_gemm_tn_workspace_bytes.restype = sz
     lib.prh_test_gemm_tn_workspace_bytes.argtypes = [i, i, i]
     lib.prh_test_gemm_tn.restype = i

@@ -55,6 +55,7 @@ struct NTParams {
   float* ws_a; float* ws_b;      // stats partials [2*row_tiles][N]
   int flags;
   int tiles_n;
+  char* wprep;                   // scratch for the split-bf16 weight image (null: fp32 MFMA core)
 };
 
 constexpr int BM = 128, BN = 128, BK = 32;
@@ -87,6 +88,115 @@ __device__ __forceinline__ float4 pro_apply(float4 a, float4 a2, float4 ka, floa
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// ---------------------------------------------------------------------------------------
+// Shared epilogue over a wave's accumulator tile acc[MT][NT] of 32x32 MFMA blocks
+// (C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5); dtype independent).
+//   rbase/cbase : global row / column of the wave tile's origin
+//   rb          : index of this wave's row tile in the statistics partial arrays
+//                 (partials cover MT*32 rows each)
+// ---------------------------------------------------------------------------------------
+template <int EPI, int MT, int NT>
+__device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[MT][NT], const NTParams& p, int rbase_,
+                                            int cbase, int rb, int lane) {
+  const int half = lane >> 5, l31 = lane & 31;
+  // Wave-uniform row base in SGPRs + 32-bit in-tile offsets: one VGPR per address instead of
+  // a 64-bit pair (the 128-register accumulator tile leaves no room for 64 address pairs).
+  const int rbase = __builtin_amdgcn_readfirstlane(rbase_);
+  float* __restrict__ Cb = p.C + (size_t)rbase * p.ldc;
+  const float* __restrict__ Eb = p.E1 != nullptr ? p.E1 + (size_t)rbase * p.lde1 : nullptr;
+  float* __restrict__ C2b = p.C2 != nullptr ? p.C2 + (size_t)rbase * p.ldc2 : nullptr;
+  const int ldc = (int)p.ldc, lde1 = (int)p.lde1, ldc2 = (int)p.ldc2;
+  const int mrows = p.M - rbase;   // rows of this wave tile that exist
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = cbase + nt * 32 + l31;
+    const bool cok = col < p.N;
+    const float bias = (p.bias != nullptr && cok) ? p.bias[col] : 0.f;
+
+    if (EPI == EPI_BIAS || EPI == EPI_BIAS_STATS) {
+      float s = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int lr = mt * 32 + crow(r, half);
+          float v = acc[mt][nt][r] + bias;
+          if ((p.flags & F_RELU_OUT) != 0) v = fmaxf(v, 0.f);
+          acc[mt][nt][r] = v;
+          if (lr < mrows && cok) {
+            Cb[lr * ldc + col] = v;
+            s += v;
+          }
+        }
+      if (EPI == EPI_BIAS_STATS) {
+        s += __shfl_xor(s, 32);
+        int nrows = mrows < 0 ? 0 : (mrows > MT * 32 ? MT * 32 : mrows);
+        const float mean = nrows > 0 ? s / (float)nrows : 0.f;
+        float m2 = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int lr = mt * 32 + crow(r, half);
+            const float d = acc[mt][nt][r] - mean;
+            if (lr < mrows) m2 = fmaf(d, d, m2);
+          }
+        m2 += __shfl_xor(m2, 32);
+        if (half == 0 && cok) {
+          p.ws_a[(size_t)rb * p.N + col] = s;
+          p.ws_b[(size_t)rb * p.N + col] = m2;
+        }
+      }
+    } else if (EPI == EPI_GATE) {
+      const float es = cok ? p.es[col] : 0.f, et = cok ? p.et[col] : 0.f;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int lr = mt * 32 + crow(r, half);
+          if (lr < mrows && cok) {
+            const float g = acc[mt][nt][r] + bias;
+            const float m = 0.5f + 0.5f / (1.f + __expf(-g));
+            const float zf = Eb[lr * lde1 + col];
+            const float rl = fmaxf(fmaf(zf, es, et), 0.f);
+            Cb[lr * ldc + col] = rl * m;
+            if ((p.flags & F_STORE_GATE) != 0) C2b[lr * ldc2 + col] = m;
+          }
+        }
+    } else {  // EPI_DGRAD
+      const bool mask = (p.flags & F_MASK) != 0, accum = (p.flags & F_ACCUM) != 0;
+      const bool need_z = mask || (p.flags & F_STATS) != 0;
+      const int ecol = (p.flags & F_E1_ROWVEC) ? 0 : col;
+      const float es = (mask && cok) ? p.es[col] : 0.f, et = (mask && cok) ? p.et[col] : 0.f;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int lr = mt * 32 + crow(r, half);
+          if (lr < mrows && cok) {
+            float v = acc[mt][nt][r] + bias;
+            if (accum) v += Cb[lr * ldc + col];
+            float z = 0.f;
+            if (need_z) z = Eb[lr * lde1 + ecol];
+            if (mask && !(fmaf(z, es, et) > 0.f)) v = 0.f;
+            Cb[lr * ldc + col] = v;
+            s1 += v;
+            s2 = fmaf(v, z, s2);
+          }
+        }
+      if ((p.flags & F_STATS) != 0) {
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (half == 0 && cok) {
+          p.ws_a[(size_t)rb * p.N + col] = s1;
+          p.ws_b[(size_t)rb * p.N + col] = s2;
+        }
+      }
+    }
+  }
+}
 
 template <int PRO, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NTParams p) {
@@ -182,97 +292,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NTParams p) {
     }
   }
 
-  // ------------------------------------------------------------------ epilogue
-  const int rbase = m0 + wm;
-  const int rb2 = tile_m * 2 + (wave >> 1);
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int col = n0 + wn + nt * 32 + l31;
-    const bool cok = col < p.N;
-    const float bias = (p.bias != nullptr && cok) ? p.bias[col] : 0.f;
-
-    if (EPI == EPI_BIAS || EPI == EPI_BIAS_STATS) {
-      float s = 0.f;
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = rbase + mt * 32 + crow(r, half);
-          float v = acc[mt][nt][r] + bias;
-          if ((p.flags & F_RELU_OUT) != 0) v = fmaxf(v, 0.f);
-          acc[mt][nt][r] = v;
-          if (row < p.M && cok) {
-            p.C[(size_t)row * p.ldc + col] = v;
-            s += v;
-          }
-        }
-      if (EPI == EPI_BIAS_STATS) {
-        s += __shfl_xor(s, 32);
-        int nrows = p.M - rbase;
-        nrows = nrows < 0 ? 0 : (nrows > 64 ? 64 : nrows);
-        const float mean = nrows > 0 ? s / (float)nrows : 0.f;
-        float m2 = 0.f;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = rbase + mt * 32 + crow(r, half);
-            const float d = acc[mt][nt][r] - mean;
-            if (row < p.M) m2 = fmaf(d, d, m2);
-          }
-        m2 += __shfl_xor(m2, 32);
-        if (half == 0 && cok) {
-          p.ws_a[(size_t)rb2 * p.N + col] = s;
-          p.ws_b[(size_t)rb2 * p.N + col] = m2;
-        }
-      }
-    } else if (EPI == EPI_GATE) {
-      const float es = cok ? p.es[col] : 0.f, et = cok ? p.et[col] : 0.f;
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = rbase + mt * 32 + crow(r, half);
-          if (row < p.M && cok) {
-            const float g = acc[mt][nt][r] + bias;
-            const float m = 0.5f + 0.5f / (1.f + __expf(-g));
-            const float zf = p.E1[(size_t)row * p.lde1 + col];
-            const float rl = fmaxf(fmaf(zf, es, et), 0.f);
-            p.C[(size_t)row * p.ldc + col] = rl * m;
-            if ((p.flags & F_STORE_GATE) != 0) p.C2[(size_t)row * p.ldc2 + col] = m;
-          }
-        }
-    } else {  // EPI_DGRAD
-      const bool mask = (p.flags & F_MASK) != 0, accum = (p.flags & F_ACCUM) != 0;
-      const bool need_z = mask || (p.flags & F_STATS) != 0;
-      const float es = (mask && cok) ? p.es[col] : 0.f, et = (mask && cok) ? p.et[col] : 0.f;
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = rbase + mt * 32 + crow(r, half);
-          if (row < p.M && cok) {
-            float v = acc[mt][nt][r] + bias;
-            if (accum) v += p.C[(size_t)row * p.ldc + col];
-            float z = 0.f;
-            if (need_z) z = p.E1[(size_t)row * p.lde1 + ((p.flags & F_E1_ROWVEC) ? 0 : col)];
-            if (mask && !(fmaf(z, es, et) > 0.f)) v = 0.f;
-            p.C[(size_t)row * p.ldc + col] = v;
-            s1 += v;
-            s2 = fmaf(v, z, s2);
-          }
-        }
-      if ((p.flags & F_STATS) != 0) {
-        s1 += __shfl_xor(s1, 32);
-        s2 += __shfl_xor(s2, 32);
-        if (half == 0 && cok) {
-          p.ws_a[(size_t)rb2 * p.N + col] = s1;
-          p.ws_b[(size_t)rb2 * p.N + col] = s2;
-        }
-      }
-    }
-  }
+  nt_epilogue<EPI, 2, 2>(acc, p, m0 + wm, n0 + wn, tile_m * 2 + (wave >> 1), lane);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -9,16 +9,16 @@
 namespace prh {
 
 // ---------------------------------------------------------------------------------------
-// BatchNorm forward statistics.  Input: per-64-row-wave-tile partials written by
-// gemm_nt<.., EPI_BIAS_STATS>: ws_sum[i][c] = sum of the tile's rows, ws_m2[i][c] = sum of
+// BatchNorm forward statistics.  Input: per-wave-tile (64 or 128 rows) partials written by
+// gemm_nt<.., EPI_BIAS_STATS>: ws_sum[i][c] = sum of the tile's `tile_rows` rows, ws_m2[i][c] = sum of
 // squared deviations from the TILE mean (Chan et al. pairwise form, so no E[x^2]-E[x]^2
 // cancellation).  Output: mean, rstd, scale = gamma*rstd, shift = beta - mean*scale, and
 // the running-stat update of nn.BatchNorm1d (momentum, UNBIASED variance).
 // grid = ceil(N/32), block = 1024 = 32 columns x 32 row groups.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void bn_fwd_finalize_kernel(
-    const float* __restrict__ ws_sum, const float* __restrict__ ws_m2, int R2, int P, int N,
-    const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
+    const float* __restrict__ ws_sum, const float* __restrict__ ws_m2, int R2, int tile_rows, int P,
+    int N, const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
     float* running_var, int64_t* nbt, float momentum, float eps, float* mean_out,
     float* rstd_out, float* scale_out, float* shift_out) {
   __shared__ double red[32][33];
@@ -41,8 +41,8 @@ __global__ __launch_bounds__(1024) void bn_fwd_finalize_kernel(
   double m2 = 0.0;
   if (ok)
     for (int i = g; i < R2; i += 32) {
-      int n = P - i * 64;
-      n = n > 64 ? 64 : n;
+      int n = P - i * tile_rows;
+      n = n > tile_rows ? tile_rows : n;
       if (n <= 0) continue;
       const double mi = (double)ws_sum[(size_t)i * N + col] / (double)n;
       const double d = mi - mu;

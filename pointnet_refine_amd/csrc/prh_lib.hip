@@ -12,7 +12,10 @@
 #include <mutex>
 #include <vector>
 
+#include <stdlib.h>
+
 #include "prh_gemm.hpp"
+#include "prh_gemm_s3.hpp"
 #include "prh_kernels.hpp"
 
 using namespace prh;
@@ -85,54 +88,101 @@ struct Arena {
   }
 };
 
-inline int stat_tiles(int P) { return 2 * cdiv(P, BM); }   // 64-row partial tiles
+// Which GEMM core serves a launch.  PRH_GEMM=fp32 forces the exact fp32 MFMA cores
+// everywhere; default "split" routes large GEMMs to the 3-plane bf16 cores (fp32-level
+// error, 2.67x higher matrix ceiling) and keeps small / odd-shaped ones on the fp32 cores.
+int g_gemm_mode = -1;   // -1: not initialised, 0: fp32 cores only, 1: split-bf16 for large GEMMs
+inline bool split_enabled() {
+  if (g_gemm_mode < 0) {
+    const char* e = getenv("PRH_GEMM");
+    g_gemm_mode = (e != nullptr && strcmp(e, "fp32") == 0) ? 0 : 1;
+  }
+  return g_gemm_mode != 0;
+}
+inline bool nt_use_s3(int M, int N, int K) { return split_enabled() && K >= 64 && N >= 128 && M >= 512; }
+inline bool tn_use_s3(int P, int Mo, int Ni) { return split_enabled() && Mo >= 128 && Ni >= 64 && P >= 2048; }
+
+// Statistics partials: `count` tiles of `rows` rows each
+struct StatInfo { int count = 0; int rows = 64; };
+inline int stat_tiles_max(int P) { return 2 * cdiv(P, BM); }   // largest count any producer writes
+
+template <typename K>
+int allow_big_lds(K kernel) {
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, S3_LDS));
+  return PRH_OK;
+}
 
 // ------------------------------------------------------------------ launch helpers
 template <int PRO, int EPI>
-int launch_nt(NTParams p, hipStream_t st) {
+int launch_nt(NTParams p, hipStream_t st, StatInfo* si = nullptr) {
   if (p.M <= 0 || p.N <= 0) return PRH_OK;
   if ((p.K & 3) || (PRO != PRO_GATE1 && (p.lda & 3)) || (p.ldw & 3) ||
       (PRO == PRO_BNBWD && (p.lda2 & 3)))
     return fail(PRH_ERR_ARG, "gemm_nt: K/lda/ldw must be multiples of 4 (K=%d lda=%ld ldw=%ld)",
                 p.K, p.lda, p.ldw);
-  p.tiles_n = cdiv(p.N, BN);
-  const long tiles = (long)p.tiles_n * cdiv(p.M, BM);
   char nm[64];
-  snprintf(nm, sizeof(nm), "gemm_nt<%d,%d> K=%d N=%d", PRO, EPI, p.K, p.N);
   // algorithmic traffic: A (+A2) read once, C written once (+E1/C_old reads), W read once
   const double by = 4.0 * ((double)p.M * p.K * (PRO == PRO_BNBWD ? 2 : (PRO == PRO_GATE1 ? 0 : 1)) +
                            (double)p.M * p.N * (EPI == EPI_GATE ? 3 : (EPI == EPI_DGRAD ? 2 : 1)) +
                            (double)p.N * p.K);
+  if constexpr (PRO != PRO_GATE1 && EPI != EPI_GATE) {
+    if (p.wprep != nullptr && nt_use_s3(p.M, p.N, p.K)) {
+      const int KT = cdiv(p.K, S3_BK), NTl = cdiv(p.N, S3_BN);
+      const long th = (long)NTl * 256 * KT * 2;
+      hipLaunchKernelGGL(prep_weights_s3_kernel, dim3((unsigned)cdiv(th, 256)), dim3(256), 0, st,
+                         p.W, p.N, p.K, p.ldw, 0, p.wprep);
+      LAUNCH_CHECK();
+      p.tiles_n = NTl;
+      const long tiles = (long)NTl * cdiv(p.M, S3_BM);
+      static const int attr_rc = allow_big_lds(gemm_nt_s3_kernel<PRO, EPI>);
+      if (attr_rc != PRH_OK) return attr_rc;
+      snprintf(nm, sizeof(nm), "gemm_nt_s3<%d,%d> K=%d N=%d", PRO, EPI, p.K, p.N);
+      ProfScope ps(nm, 2.0 * p.M * (double)p.N * p.K, by, st);
+      hipLaunchKernelGGL((gemm_nt_s3_kernel<PRO, EPI>), dim3((unsigned)tiles), dim3(512), S3_LDS, st,
+                         p, (const char*)p.wprep);
+      LAUNCH_CHECK();
+      if (si) { si->count = 2 * cdiv(p.M, S3_BM); si->rows = 128; }
+      return PRH_OK;
+    }
+  }
+  p.tiles_n = cdiv(p.N, BN);
+  const long tiles = (long)p.tiles_n * cdiv(p.M, BM);
+  snprintf(nm, sizeof(nm), "gemm_nt<%d,%d> K=%d N=%d", PRO, EPI, p.K, p.N);
   ProfScope ps(nm, 2.0 * p.M * (double)p.N * p.K, by, st);
   hipLaunchKernelGGL((gemm_nt_kernel<PRO, EPI>), dim3((unsigned)tiles), dim3(256), 0, st, p);
   LAUNCH_CHECK();
+  if (si) { si->count = 2 * cdiv(p.M, BM); si->rows = 64; }
   return PRH_OK;
 }
 
-struct TNPlan { int tiles_m, tiles_n, splits, rows_per_split; };
-inline TNPlan tn_plan(int P, int Mo, int Ni) {
+struct TNPlan { int tiles_m, tiles_n, splits, rows_per_split; bool s3; };
+inline TNPlan tn_plan(int P, int Mo, int Ni, bool allow_s3) {
   TNPlan pl;
-  pl.tiles_m = cdiv(Mo, 128);
-  pl.tiles_n = cdiv(Ni, 128);
+  pl.s3 = allow_s3 && tn_use_s3(P, Mo, Ni);
+  const int tile = pl.s3 ? 256 : 128, bk = pl.s3 ? S3_BK : BK;
+  pl.tiles_m = cdiv(Mo, tile);
+  pl.tiles_n = cdiv(Ni, tile);
   const int tiles = pl.tiles_m * pl.tiles_n;
-  int s = cdiv(1024, tiles);
-  const int smax = cdiv(P, 512) < 1 ? 1 : cdiv(P, 512);
+  int s = cdiv(pl.s3 ? 768 : 1024, tiles);
+  const int minrows = pl.s3 ? 1024 : 512;
+  const int smax = cdiv(P, minrows) < 1 ? 1 : cdiv(P, minrows);
   if (s > smax) s = smax;
   if (s < 1) s = 1;
   int rps = cdiv(P, s);
-  rps = cdiv(rps, BK) * BK;
-  if (rps < BK) rps = BK;
+  rps = cdiv(rps, bk) * bk;
+  if (rps < bk) rps = bk;
   pl.splits = cdiv(P, rps) < 1 ? 1 : cdiv(P, rps);
   pl.rows_per_split = rps;
   return pl;
 }
-inline size_t tn_slab_floats(int P, int Mo, int Ni) {
-  TNPlan pl = tn_plan(P, Mo, Ni);
-  return (size_t)pl.splits * Mo * Ni;
+inline size_t tn_slab_floats(int P, int Mo, int Ni) {   // upper bound over both cores
+  const size_t a = (size_t)tn_plan(P, Mo, Ni, true).splits, b = (size_t)tn_plan(P, Mo, Ni, false).splits;
+  return (a > b ? a : b) * Mo * Ni;
 }
 inline size_t tn_colsum_floats(int P, int Mo, int Ni) {
-  TNPlan pl = tn_plan(P, Mo, Ni);
-  return (size_t)pl.splits * Mo;
+  const size_t a = (size_t)tn_plan(P, Mo, Ni, true).splits, b = (size_t)tn_plan(P, Mo, Ni, false).splits;
+  return (a > b ? a : b) * Mo;
 }
 
 // C[Mo,Ni] (ld ldc) = proA(A)^T proB(B); colsum_out[Mo] = column sums of proA(A) (optional)
@@ -140,10 +190,10 @@ template <int PROA, int PROB>
 int launch_tn(TNParams p, float* slab, float* colsum_slab, float* C, long ldc, float* colsum_out,
               hipStream_t st) {
   if (p.Mo <= 0 || p.Ni <= 0) return PRH_OK;
-  if ((p.Mo & 3) || (p.Ni & 3) || (p.lda & 3) || (PROB != PRO_GATE1 && (p.ldb & 3)))
+  TNPlan pl = tn_plan(p.P, p.Mo, p.Ni, PROB != PRO_GATE1);
+  if (!pl.s3 && ((p.Mo & 3) || (p.Ni & 3) || (p.lda & 3) || (PROB != PRO_GATE1 && (p.ldb & 3))))
     return fail(PRH_ERR_ARG, "gemm_tn: Mo/Ni/lda/ldb must be multiples of 4 (Mo=%d Ni=%d)", p.Mo,
                 p.Ni);
-  TNPlan pl = tn_plan(p.P, p.Mo, p.Ni);
   p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n; p.splits = pl.splits;
   p.rows_per_split = pl.rows_per_split;
   p.slab = slab;
@@ -151,11 +201,25 @@ int launch_tn(TNParams p, float* slab, float* colsum_slab, float* C, long ldc, f
   const long blocks = (long)pl.tiles_m * pl.tiles_n * pl.splits;
   {
     char nm[64];
-    snprintf(nm, sizeof(nm), "gemm_tn<%d,%d> Mo=%d Ni=%d", PROA, PROB, p.Mo, p.Ni);
     const double by = 4.0 * ((double)p.P * p.Mo * (PROA == PRO_BNBWD ? 2 : 1) +
                              (double)p.P * (PROB == PRO_GATE1 ? 1 : p.Ni) + (double)p.Mo * p.Ni);
-    ProfScope ps(nm, 2.0 * p.P * (double)p.Mo * p.Ni, by, st);
-    hipLaunchKernelGGL((gemm_tn_kernel<PROA, PROB>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    bool done = false;
+    if constexpr (PROB != PRO_GATE1) {
+      if (pl.s3) {
+        static const int attr_rc = allow_big_lds(gemm_tn_s3_kernel<PROA, PROB>);
+        if (attr_rc != PRH_OK) return attr_rc;
+        snprintf(nm, sizeof(nm), "gemm_tn_s3<%d,%d> Mo=%d Ni=%d", PROA, PROB, p.Mo, p.Ni);
+        ProfScope ps(nm, 2.0 * p.P * (double)p.Mo * p.Ni, by, st);
+        hipLaunchKernelGGL((gemm_tn_s3_kernel<PROA, PROB>), dim3((unsigned)blocks), dim3(512), S3_LDS,
+                           st, p);
+        done = true;
+      }
+    }
+    if (!done) {
+      snprintf(nm, sizeof(nm), "gemm_tn<%d,%d> Mo=%d Ni=%d", PROA, PROB, p.Mo, p.Ni);
+      ProfScope ps(nm, 2.0 * p.P * (double)p.Mo * p.Ni, by, st);
+      hipLaunchKernelGGL((gemm_tn_kernel<PROA, PROB>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    }
   }
   LAUNCH_CHECK();
   if (C != nullptr) {
@@ -228,23 +292,36 @@ int check_stack(const prh_bn_layer* ly, int L) {
 struct StackWS {
   float* xpad = nullptr;    // [P, cin0p] when cin0 % 4 != 0
   float* w0pad = nullptr;   // [cout0, cin0p]
-  float* ws_a = nullptr;    // stats partials [stat_tiles][maxc]
+  float* ws_a = nullptr;    // stats partials [stat_tiles_max][maxc]
   float* ws_b = nullptr;
+  char* wprep = nullptr;    // split-bf16 weight image of the layer being run
 };
-bool stack_ws_carve(Arena& a, StackWS& w, int P, const prh_bn_layer* ly, int L, int maxc) {
+inline size_t wprep_floats(const prh_bn_layer* ly, int L, int extra_n, int extra_k) {
+  size_t m = s3_weight_bytes(extra_n, extra_k), t = s3_weight_bytes(extra_k, extra_n);
+  m = t > m ? t : m;
+  for (int l = 0; l < L; ++l) {
+    const int ci = (int)align_up((size_t)ly[l].cin, 4);
+    size_t a = s3_weight_bytes(ly[l].cout, ci), b = s3_weight_bytes(ci, ly[l].cout);
+    m = a > m ? a : m; m = b > m ? b : m;
+  }
+  return m / sizeof(float) + 64;
+}
+bool stack_ws_carve(Arena& a, StackWS& w, int P, const prh_bn_layer* ly, int L, int maxc,
+                    int extra_n = 0, int extra_k = 0) {
   StackDims d = stack_dims(ly, L);
   if (d.cin0p != d.cin0) { w.xpad = a.f((size_t)P * d.cin0p); w.w0pad = a.f((size_t)ly[0].cout * d.cin0p); }
-  w.ws_a = a.f((size_t)stat_tiles(P) * maxc);
-  w.ws_b = a.f((size_t)stat_tiles(P) * maxc);
+  w.ws_a = a.f((size_t)stat_tiles_max(P) * maxc);
+  w.ws_b = a.f((size_t)stat_tiles_max(P) * maxc);
+  w.wprep = (char*)a.f(wprep_floats(ly, L, extra_n, extra_k));
   return a.ok;
 }
 
 int bn_coeffs(const prh_bn_layer& ly, int P, int training, float momentum, float eps,
-              const float* ws_a, const float* ws_b, float* mean, float* rstd, float* scale,
-              float* shift, hipStream_t st) {
+              const float* ws_a, const float* ws_b, StatInfo si, float* mean, float* rstd,
+              float* scale, float* shift, hipStream_t st) {
   if (training) {
     hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(cdiv(ly.cout, 32)), dim3(1024), 0, st, ws_a,
-                       ws_b, stat_tiles(P), P, ly.cout, ly.gamma, ly.beta, ly.running_mean,
+                       ws_b, si.count, si.rows, P, ly.cout, ly.gamma, ly.beta, ly.running_mean,
                        ly.running_var, ly.num_batches_tracked, momentum, eps, mean, rstd, scale,
                        shift);
   } else {
@@ -271,18 +348,19 @@ int stack_forward(const prh_bn_layer* ly, int L, const float* x, int P, int trai
     NTParams p; memset(&p, 0, sizeof(p));
     p.M = P; p.N = ly[l].cout; p.bias = ly[l].b;
     p.C = z_cat + d.off[l]; p.ldc = ldz;
-    p.ws_a = w.ws_a; p.ws_b = w.ws_b;
+    p.ws_a = w.ws_a; p.ws_b = w.ws_b; p.wprep = w.wprep;
+    StatInfo si;
     if (l == 0) {
       p.A = x0; p.lda = ldx; p.W = w0; p.ldw = k0; p.K = k0;
-      if (training) TRY((launch_nt<PRO_NONE, EPI_BIAS_STATS>(p, st)));
+      if (training) TRY((launch_nt<PRO_NONE, EPI_BIAS_STATS>(p, st, &si)));
       else TRY((launch_nt<PRO_NONE, EPI_BIAS>(p, st)));
     } else {
       p.A = z_cat + d.off[l - 1]; p.lda = ldz; p.W = ly[l].w; p.ldw = ly[l].cin; p.K = ly[l].cin;
       p.pa = scale + d.off[l - 1]; p.pb = shift + d.off[l - 1];
-      if (training) TRY((launch_nt<PRO_BNRELU, EPI_BIAS_STATS>(p, st)));
+      if (training) TRY((launch_nt<PRO_BNRELU, EPI_BIAS_STATS>(p, st, &si)));
       else TRY((launch_nt<PRO_BNRELU, EPI_BIAS>(p, st)));
     }
-    TRY(bn_coeffs(ly[l], P, training, momentum, eps, w.ws_a, w.ws_b, mean + d.off[l],
+    TRY(bn_coeffs(ly[l], P, training, momentum, eps, w.ws_a, w.ws_b, si, mean + d.off[l],
                   rstd + d.off[l], scale + d.off[l], shift + d.off[l], st));
   }
   return PRH_OK;
@@ -300,7 +378,7 @@ int stack_backward(const prh_bn_layer* ly, int L, const float* x, int P, int tra
                    float* dy_cat, long lddy, const float* z_cat, long ldz, const float* scale,
                    const float* shift, const float* mean, const float* rstd,
                    const prh_bn_layer_grad* gr, float* dx, StackWS& w, StackBwdScratch& sc,
-                   hipStream_t st) {
+                   StatInfo si, hipStream_t st) {
   StackDims d = stack_dims(ly, L);
   const float* x0 = x; long ldx = d.cin0; int k0 = d.cin0;
   if (d.cin0p != d.cin0) { x0 = w.xpad; ldx = d.cin0p; k0 = d.cin0p; }   // xpad filled by caller
@@ -308,7 +386,7 @@ int stack_backward(const prh_bn_layer* ly, int L, const float* x, int P, int tra
     const int co = ly[l].cout, o = d.off[l];
     // 1. statistics -> BN-backward coefficients, dgamma, dbeta, dbias
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(co, 32)), dim3(1024), 0, st, w.ws_a,
-                       w.ws_b, stat_tiles(P), P, co, ly[l].gamma, mean + o, rstd + o, training,
+                       w.ws_b, si.count, P, co, ly[l].gamma, mean + o, rstd + o, training,
                        sc.ca, sc.cb, sc.cc, gr ? gr[l].dgamma : nullptr, gr ? gr[l].dbeta : nullptr,
                        gr ? gr[l].db : nullptr);
     LAUNCH_CHECK();
@@ -341,9 +419,9 @@ int stack_backward(const prh_bn_layer* ly, int L, const float* x, int P, int tra
       p.C = dy_cat + d.off[l - 1]; p.ldc = lddy;
       p.E1 = z_cat + d.off[l - 1]; p.lde1 = ldz;
       p.es = scale + d.off[l - 1]; p.et = shift + d.off[l - 1];
-      p.ws_a = w.ws_a; p.ws_b = w.ws_b;
+      p.ws_a = w.ws_a; p.ws_b = w.ws_b; p.wprep = w.wprep;
       p.flags = F_ACCUM | F_MASK | F_STATS;
-      TRY((launch_nt<PRO_BNBWD, EPI_DGRAD>(p, st)));
+      TRY((launch_nt<PRO_BNBWD, EPI_DGRAD>(p, st, &si)));
     } else if (dx != nullptr) {
       // dx = dz_0 W_0  (W_0^T is [cin0p, cout] with zero pad rows)
       const float* w0 = ly[0].w; int kk = d.cin0;
@@ -390,8 +468,9 @@ void stack_bwd_scratch_carve(Arena& a, StackBwdScratch& sc, int P, const prh_bn_
 }
 
 // ---- workspace layouts of the entry points (measure with Arena(), carve with Arena(ptr,n))
-struct LinearBwdWS { float* wT; float* slab; float* cslab; };
+struct LinearBwdWS { float* wT; float* slab; float* cslab; char* wprep; };
 void linear_bwd_carve(Arena& a, LinearBwdWS& w, int rows, int k, int n) {
+  w.wprep = (char*)a.f(s3_weight_bytes(k, n) / sizeof(float) + 64);
   w.wT = a.f((size_t)k * n);
   w.slab = a.f(tn_slab_floats(rows, n, k));
   w.cslab = a.f(tn_colsum_floats(rows, n, k));
@@ -405,7 +484,7 @@ void mlp_carve(Arena& a, MlpWS& m, int P, const prh_bn_layer* ly, int L) {
 }
 struct EncWS { StackWS w; StackBwdScratch sc; float* fslab; float* fcslab; float* dy_cat; float* dU; float* gsum_a; float* gsum_b; };
 void enc_carve(Arena& a, EncWS& e, int P, const prh_bn_layer* conv, int cat, int od, bool backward) {
-  stack_ws_carve(a, e.w, P, conv, 5, cat > od ? cat : od);
+  stack_ws_carve(a, e.w, P, conv, 5, cat > od ? cat : od, od, cat);
   if (!backward) return;
   stack_bwd_scratch_carve(a, e.sc, P, conv, 5, (size_t)od * cat, cat > od ? cat : od);
   const size_t fs = tn_slab_floats(P, od, cat), gs = tn_slab_floats(P, od, 64);
@@ -424,16 +503,30 @@ void enc_carve(Arena& a, EncWS& e, int P, const prh_bn_layer* conv, int cat, int
 extern "C" {
 
 const char* prh_last_error(void) { return g_err; }
+int prh_set_gemm_mode(int mode) {
+  if (mode != 0 && mode != 1) return fail(PRH_ERR_ARG, "gemm mode must be 0 (fp32) or 1 (split-bf16)");
+  g_gemm_mode = mode;
+  return PRH_OK;
+}
+int prh_get_gemm_mode(void) { return split_enabled() ? 1 : 0; }
 const char* prh_version(void) { return "pointnet_refine_hip 0.1 (gfx950, fp32 MFMA 32x32x2)"; }
 
 // ------------------------------------------------------------------ Linear
+size_t prh_linear_forward_workspace_bytes(int rows, int k, int n) {
+  (void)rows;
+  return s3_weight_bytes(n, k) + 512;
+}
+
 int prh_linear_forward(const float* x, long ldx, const float* w, const float* b, float* y,
-                       int rows, int k, int n, int relu, int device, void* stream) {
+                       int rows, int k, int n, int relu, void* workspace, size_t workspace_bytes,
+                       int device, void* stream) {
   if (!x || !w || !y || rows < 0 || k <= 0 || n <= 0) return fail(PRH_ERR_ARG, "linear_forward: bad argument");
   HIP_TRY(hipSetDevice(device));
   NTParams p; memset(&p, 0, sizeof(p));
   p.A = x; p.lda = ldx; p.W = w; p.ldw = k; p.C = y; p.ldc = n;
   p.M = rows; p.N = n; p.K = k; p.bias = b; p.flags = relu ? F_RELU_OUT : 0;
+  if (workspace != nullptr && workspace_bytes >= s3_weight_bytes(n, k) + 256)
+    p.wprep = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   return launch_nt<PRO_NONE, EPI_BIAS>(p, (hipStream_t)stream);
 }
 
@@ -459,6 +552,7 @@ int prh_linear_backward(const float* x, long ldx, const float* w, const float* d
     TRY(transpose(w, n, k, wT, st));   // wT [k, n]
     NTParams p; memset(&p, 0, sizeof(p));
     p.A = dy; p.lda = n; p.W = wT; p.ldw = n; p.C = dx; p.ldc = k; p.M = rows; p.N = k; p.K = n;
+    p.wprep = lw.wprep;
     TRY((launch_nt<PRO_NONE, EPI_BIAS>(p, st)));
   }
   if (dw != nullptr || db != nullptr) {
@@ -535,14 +629,9 @@ int prh_mlp_stack_backward(const prh_bn_layer* layers, int n_layers, int relu_la
                      (long)co, z_cat + o, ldz, bn_scale + o, bn_shift + o, P, co, relu_last,
                      dy_cat + o, ldz, w.ws_a, w.ws_b);
   LAUNCH_CHECK();
-  // ws partial count of the elementwise kernel is cdiv(P,64); pad entry (if any) of the
-  // GEMM-shaped count must read as zero
-  if (stat_tiles(P) > cdiv(P, 64)) {
-    HIP_TRY(hipMemsetAsync(w.ws_a + (size_t)cdiv(P, 64) * co, 0, (size_t)co * sizeof(float), st));
-    HIP_TRY(hipMemsetAsync(w.ws_b + (size_t)cdiv(P, 64) * co, 0, (size_t)co * sizeof(float), st));
-  }
+  StatInfo si; si.count = cdiv(P, 64); si.rows = 64;
   return stack_backward(layers, L, x, P, training, dy_cat, ldz, z_cat, ldz, bn_scale, bn_shift,
-                        bn_mean, bn_rstd, grads, dx, w, sc, st);
+                        bn_mean, bn_rstd, grads, dx, w, sc, si, st);
 }
 
 // ------------------------------------------------------------------ encoder
@@ -608,10 +697,11 @@ int prh_encoder_forward(const prh_encoder_params* prm, const float* ctx, int B, 
     p.A = sv->z_cat; p.lda = cat; p.W = prm->fusion.w; p.ldw = cat; p.K = cat;
     p.pa = sv->bn_scale; p.pb = sv->bn_shift;
     p.M = P; p.N = od; p.bias = prm->fusion.b; p.C = sv->z_fus; p.ldc = od;
-    p.ws_a = w.ws_a; p.ws_b = w.ws_b;
-    if (training) TRY((launch_nt<PRO_BNRELU, EPI_BIAS_STATS>(p, st)));
+    p.ws_a = w.ws_a; p.ws_b = w.ws_b; p.wprep = w.wprep;
+    StatInfo si;
+    if (training) TRY((launch_nt<PRO_BNRELU, EPI_BIAS_STATS>(p, st, &si)));
     else TRY((launch_nt<PRO_BNRELU, EPI_BIAS>(p, st)));
-    TRY(bn_coeffs(prm->fusion, P, training, momentum, eps, w.ws_a, w.ws_b, sv->bn_mean + cat,
+    TRY(bn_coeffs(prm->fusion, P, training, momentum, eps, w.ws_a, w.ws_b, si, sv->bn_mean + cat,
                   sv->bn_rstd + cat, sv->bn_scale + cat, sv->bn_shift + cat, st));
   }
   // intensity gate GEMM + BN/ReLU/gate combine                     src/model.py:42,51,54-55
@@ -665,12 +755,8 @@ int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B,
                      d_gfeat, sv->argmax, sv->z_fus, sv->gate, sv->bn_scale + cat,
                      sv->bn_shift + cat, P, N, od, d_fused, w.ws_a, w.ws_b);
   LAUNCH_CHECK();
-  if (stat_tiles(P) > cdiv(P, 64)) {
-    HIP_TRY(hipMemsetAsync(w.ws_a + (size_t)cdiv(P, 64) * od, 0, (size_t)od * sizeof(float), st));
-    HIP_TRY(hipMemsetAsync(w.ws_b + (size_t)cdiv(P, 64) * od, 0, (size_t)od * sizeof(float), st));
-  }
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(od, 32)), dim3(1024), 0, st, w.ws_a, w.ws_b,
-                     stat_tiles(P), P, od, prm->fusion.gamma, sv->bn_mean + cat, sv->bn_rstd + cat,
+                     cdiv(P, 64), P, od, prm->fusion.gamma, sv->bn_mean + cat, sv->bn_rstd + cat,
                      training, sc.ca, sc.cb, sc.cc, gr->fusion.dgamma, gr->fusion.dbeta,
                      gr->fusion.db);
   LAUNCH_CHECK();
@@ -691,6 +777,7 @@ int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B,
     p.A = d_fused; p.lda = od; p.A2 = sv->z_fus; p.lda2 = od; p.pa = sc.ca; p.pb = sc.cb; p.pc = sc.cc;
     p.W = sc.wT; p.ldw = od; p.M = P; p.N = cat; p.K = od;
     p.C = dy_cat; p.ldc = cat; p.E1 = sv->z_cat; p.lde1 = cat; p.es = sv->bn_scale; p.et = sv->bn_shift;
+    p.wprep = w.wprep;
     p.flags = F_MASK;
     TRY((launch_nt<PRO_BNBWD, EPI_DGRAD>(p, st)));
   }
@@ -701,15 +788,13 @@ int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B,
                        dy_cat + o5, (long)cat, sv->z_cat + o5, (long)cat, sv->bn_scale + o5,
                        sv->bn_shift + o5, P, c5, 0, dy_cat + o5, (long)cat, w.ws_a, w.ws_b);
     LAUNCH_CHECK();
-    if (stat_tiles(P) > cdiv(P, 64)) {
-      HIP_TRY(hipMemsetAsync(w.ws_a + (size_t)cdiv(P, 64) * c5, 0, (size_t)c5 * sizeof(float), st));
-      HIP_TRY(hipMemsetAsync(w.ws_b + (size_t)cdiv(P, 64) * c5, 0, (size_t)c5 * sizeof(float), st));
-    }
   }
   // (3) conv5..conv1
   float* dx = d_ctx;
+  StatInfo si5; si5.count = cdiv(P, 64); si5.rows = 64;
   TRY(stack_backward(prm->conv, 5, ctx, P, training, dy_cat, (long)cat, sv->z_cat, (long)cat,
-                     sv->bn_scale, sv->bn_shift, sv->bn_mean, sv->bn_rstd, gr->conv, dx, w, sc, st));
+                     sv->bn_scale, sv->bn_shift, sv->bn_mean, sv->bn_rstd, gr->conv, dx, w, sc, si5,
+                     st));
 
   // (4) intensity gate: dW2 = dG^T u, db2 = colsum dG; dU = dG W2 masked by u>0 with
   //     column sums (db1) and intensity-weighted column sums (dw1)
@@ -724,9 +809,10 @@ int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B,
     p.C = dU; p.ldc = 64; p.E1 = ctx + 3; p.lde1 = C; p.es = prm->gate_w1; p.et = prm->gate_b1;
     p.ws_a = w.ws_a; p.ws_b = w.ws_b;
     p.flags = F_MASK | F_STATS | F_E1_ROWVEC;
-    TRY((launch_nt<PRO_NONE, EPI_DGRAD>(p, st)));
+    StatInfo sig;
+    TRY((launch_nt<PRO_NONE, EPI_DGRAD>(p, st, &sig)));
     hipLaunchKernelGGL(partials_reduce_kernel, dim3(2), dim3(1024), 0, st, w.ws_a, w.ws_b,
-                       stat_tiles(P), 64, gr->d_gate_b1 ? gr->d_gate_b1 : gsum_a,
+                       sig.count, 64, gr->d_gate_b1 ? gr->d_gate_b1 : gsum_a,
                        gr->d_gate_w1 ? gr->d_gate_w1 : gsum_b);
     LAUNCH_CHECK();
     if (d_ctx != nullptr) {
@@ -775,11 +861,13 @@ int prh_profile_read(int i, char* name, int name_len, float* ms, double* flops, 
 }
 
 // ------------------------------------------------------------------ raw cores for tests
-int prh_test_gemm_nt(const float* a, const float* w, float* c, int m, int n, int k, int device,
-                     void* stream) {
+int prh_test_gemm_nt(const float* a, const float* w, float* c, int m, int n, int k, void* workspace,
+                     size_t workspace_bytes, int device, void* stream) {
   HIP_TRY(hipSetDevice(device));
   NTParams p; memset(&p, 0, sizeof(p));
   p.A = a; p.lda = k; p.W = w; p.ldw = k; p.C = c; p.ldc = n; p.M = m; p.N = n; p.K = k;
+  if (workspace != nullptr && workspace_bytes >= s3_weight_bytes(n, k) + 256)
+    p.wprep = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   return launch_nt<PRO_NONE, EPI_BIAS>(p, (hipStream_t)stream);
 }
 size_t prh_test_gemm_tn_workspace_bytes(int p, int mo, int ni) {

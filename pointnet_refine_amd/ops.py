@@ -75,8 +75,10 @@ class LinearFn(torch.autograd.Function):
         w = w.contiguous()
         rows = x2.shape[0]
         y = torch.empty((rows, n), dtype=torch.float32, device=x.device)
-        L.check(L.lib().prh_linear_forward(_p(x2), k, _p(w), _p(b), _p(y), rows, k, n, 0,
-                                           x.device.index, _stream(x.device)), "prh_linear_forward")
+        ws = _ws(x.device, L.lib().prh_linear_forward_workspace_bytes(rows, k, n))
+        L.check(L.lib().prh_linear_forward(_p(x2), k, _p(w), _p(b), _p(y), rows, k, n, 0, _p(ws),
+                                           ws.numel(), x.device.index, _stream(x.device)),
+                "prh_linear_forward")
         ctx.save_for_backward(x2, w)
         ctx.has_bias = b is not None
         ctx.xshape = x.shape

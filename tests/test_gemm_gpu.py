@@ -13,14 +13,20 @@ def _p(t):
     return C.c_void_p(t.data_ptr())
 
 
-@pytest.fixture(scope="module")
-def lib():
+@pytest.fixture(scope="module", params=[0, 1], ids=["fp32", "split"])
+def lib(request):
+    """Every case runs on the exact fp32 MFMA cores and on the split-bf16 cores."""
     from pointnet_refine_amd import _lib
-    return _lib.lib()
+    l = _lib.lib()
+    old = l.prh_get_gemm_mode()
+    assert l.prh_set_gemm_mode(request.param) == 0
+    yield l
+    l.prh_set_gemm_mode(old)
 
 
 @pytest.mark.parametrize("m,n,k", [(128, 128, 32), (1, 4, 4), (257, 64, 64), (1000, 1984, 1024),
-                                   (333, 100, 1984), (4096, 1024, 1984), (70, 3, 128)])
+                                   (333, 100, 1984), (4096, 1024, 1984), (70, 3, 128), (777, 300, 72),
+                                   (512, 128, 64), (1031, 1984, 1024)])
 def test_gemm_nt(lib, m, n, k):
     g = torch.Generator(device="cuda").manual_seed(m * 7 + n * 3 + k)
     a = torch.randn(m, k, device="cuda", generator=g)
@@ -29,7 +35,9 @@ def test_gemm_nt(lib, m, n, k):
     a[:, 0] += torch.arange(m, device="cuda") * 0.01
     c = torch.full((m, n), float("nan"), device="cuda")
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    rc = lib.prh_test_gemm_nt(_p(a), _p(w), _p(c), m, n, k, 0, st)
+    nb = lib.prh_linear_forward_workspace_bytes(m, k, n)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    rc = lib.prh_test_gemm_nt(_p(a), _p(w), _p(c), m, n, k, _p(ws), nb, 0, st)
     assert rc == 0, lib.prh_last_error()
     ref = a.double() @ w.double().t()
     tol = 2e-6 * k ** 0.5 * float(ref.abs().max() / k ** 0.5 + 1)
@@ -37,7 +45,8 @@ def test_gemm_nt(lib, m, n, k):
 
 
 @pytest.mark.parametrize("p,mo,ni", [(32, 128, 128), (1, 4, 4), (1000, 64, 4), (5000, 1024, 1984),
-                                     (100000, 128, 64), (777, 256, 1024), (65, 1024, 64)])
+                                     (100000, 128, 64), (777, 256, 1024), (65, 1024, 64), (4099, 300, 260),
+                                     (20000, 1024, 1984)])
 def test_gemm_tn(lib, p, mo, ni):
     g = torch.Generator(device="cuda").manual_seed(p + mo + ni)
     a = torch.randn(p, mo, device="cuda", generator=g)
@@ -57,5 +66,31 @@ def test_gemm_tn(lib, p, mo, ni):
 def test_gemm_rejects_unaligned_k(lib):
     a = torch.randn(8, 6, device="cuda")
     c = torch.empty(8, 8, device="cuda")
-    rc = lib.prh_test_gemm_nt(_p(a), _p(a), _p(c), 8, 8, 6, 0, C.c_void_p(0))
+    rc = lib.prh_test_gemm_nt(_p(a), _p(a), _p(c), 8, 8, 6, None, 0, 0, C.c_void_p(0))
     assert rc == -1 and b"multiples of 4" in lib.prh_last_error()
+
+
+def test_split_core_is_fp32_accurate():
+    """The split-bf16 core (3 planes, 6 MFMA products) must match fp64 as closely as the
+    exact fp32 MFMA core does: relative L2 error below 1e-6 on a K=1984 contraction with a
+    wide dynamic range (values from 1e-6 to 1e+4, no scaling assumptions)."""
+    from pointnet_refine_amd import _lib
+    lib = _lib.lib()
+    m, n, k = 2048, 1024, 1984
+    g = torch.Generator(device="cuda").manual_seed(5)
+    a = torch.randn(m, k, device="cuda", generator=g) * torch.exp(torch.randn(m, 1, device="cuda", generator=g) * 3)
+    w = torch.randn(n, k, device="cuda", generator=g) * torch.exp(torch.randn(n, 1, device="cuda", generator=g) * 2) * 0.02
+    ref = a.double() @ w.double().t()
+    nb = lib.prh_linear_forward_workspace_bytes(m, k, n)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    errs = {}
+    old = lib.prh_get_gemm_mode()
+    for mode in (0, 1):
+        lib.prh_set_gemm_mode(mode)
+        c = torch.empty(m, n, device="cuda")
+        assert lib.prh_test_gemm_nt(_p(a), _p(w), _p(c), m, n, k, _p(ws), nb, 0, st) == 0
+        errs[mode] = float((c.double() - ref).norm() / ref.norm())
+    lib.prh_set_gemm_mode(old)
+    print("rel-L2 error vs fp64: fp32 core %.3e, split core %.3e" % (errs[0], errs[1]))
+    assert errs[0] < 1e-6 and errs[1] < 1e-6
