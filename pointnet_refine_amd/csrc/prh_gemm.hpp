@@ -62,6 +62,16 @@ constexpr int BM = 128, BN = 128, BK = 32;
 
 __device__ __forceinline__ int crow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
+// XCD-aware block id: workgroups are dealt round-robin over the 8 XCDs (b % 8 labels the
+// blocks that share an L2), so give each XCD a CONTIGUOUS range of tile ids.  With the column
+// tile fastest in the id, the column tiles of one row tile then run side by side on one L2 and
+// the activation tile (the large, HBM-resident operand) is fetched once instead of once per
+// column tile.  Bijective for any grid size; speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int b, int nb) {
+  const int q = nb >> 3, r = nb & 7, x = b & 7, i = b >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
 // swizzled LDS float offset of 16-B slot `slot` (0..7) in row `row` of a [rows][32] tile.
 // ds_read_b128 lane groups hold 16 lanes with distinct row mod 16 -> conflict free.
 __device__ __forceinline__ int lds_off(int row, int slot) {
@@ -207,7 +217,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NTParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-  const int tile_n = blockIdx.x % p.tiles_n, tile_m = blockIdx.x / p.tiles_n;
+  const int vb = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = vb % p.tiles_n, tile_m = vb / p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int sr = tid >> 3;         // staging row 0..31 (+32*j)

@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "prh_gemm.hpp"
 
 namespace prh {
@@ -141,12 +143,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
-  const int tile_n = blockIdx.x % p.tiles_n, tile_m = blockIdx.x / p.tiles_n;
+  const int vb = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = vb % p.tiles_n, tile_m = vb / p.tiles_n;
   const int m0 = tile_m * S3_BM, n0 = tile_n * S3_BN;
   const int KT = (p.K + S3_BK - 1) / S3_BK;
 
   const int sc = (tid & 3) * 4;      // staging k offset (float4)
   const int sr = tid >> 2;           // staging row 0..127 (+128)
+  const int KP = (KT + 2) * S3_BK;   // padded length of the coefficient vectors in LDS
+  float* coef = reinterpret_cast<float*>(smem + S3_LDS);
 
   f32x16 acc[4][2];
 #pragma unroll
@@ -156,7 +161,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[2], ra2[2];
+  // Two staging register sets: tile t lives in set t&1.  Iteration kt converts tile kt+1
+  // (loaded one iteration earlier, so its data has landed and the conversion VALU work has no
+  // wait in front of it and can be interleaved with the MFMAs of tile kt) and issues the
+  // loads of tile kt+2.
+  float4 ra[2][2], ra2[2][2];
   const char* wsrc = Wp + (size_t)tile_n * KT * S3_OPER + tid * 16;
   // wave-uniform LDS offset of this wave's 1-KB slice of a W plane (LDS-DMA adds lane*16)
   const int wdst = S3_OPER + __builtin_amdgcn_readfirstlane(wave) * 1024;
@@ -164,38 +173,56 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
   // W planes: pre-split, pre-swizzled image -> straight global->LDS DMA (no registers, no
   // ds_write); the __syncthreads() that ends the iteration waits for it (vmcnt).
   auto dma_w = [&](int kt, char* st) {
-    const char* q = wsrc + (size_t)kt * S3_OPER;
+    const char* q = wsrc + (size_t)(kt < KT ? kt : KT - 1) * S3_OPER;   // tail: harmless re-copy
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)(q + pl * S3_PLANE),
           (__attribute__((address_space(3))) void*)(st + wdst + pl * S3_PLANE), 16, 0, 0);
   };
-  auto load_tile = [&](int kt) {
-    const int k = kt * S3_BK + sc;
-    const bool kok = k < p.K;
+  // A via buffer loads: descriptor = this block's 256 rows (hardware returns 0 beyond them,
+  // so no exec-mask branches and no address clamps), per-lane 32-bit byte offsets computed
+  // once; the k advance is added to the per-lane offset (NOT the scalar offset, which the
+  // hardware leaves out of its range check: the prefetch of tile kt+2 runs past K).
+  int arows = p.M - m0; arows = arows > S3_BM ? S3_BM : arows;
+  // extent = up to column K of the last row (A may be a column slice of a wider tensor, so
+  // "arows * lda" would reach past the end of the allocation on the last row)
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.A + (size_t)m0 * p.lda), 0, (int)(((size_t)(arows - 1) * p.lda + p.K) * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((PRO == PRO_BNBWD ? p.A2 : p.A) + (size_t)m0 * (PRO == PRO_BNBWD ? p.lda2 : p.lda)), 0,
+      (int)(((size_t)(arows - 1) * (PRO == PRO_BNBWD ? p.lda2 : p.lda) + p.K) * 4), 0x00020000);
+  int voA[2], voA2[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    voA[j] = ((sr + 128 * j) * (int)p.lda + sc) * 4;
+    voA2[j] = ((sr + 128 * j) * (int)p.lda2 + sc) * 4;
+  }
+  auto load_tile = [&](int kt, float4 (&r)[2], float4 (&r2)[2]) {
+    const int so = kt * (S3_BK * 4);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int row = m0 + sr + 128 * j;
-      const bool ok = kok && row < p.M;
-      ra[j] = ok ? ldg4(p.A + (size_t)row * p.lda + k) : zero4();
-      if (PRO == PRO_BNBWD) ra2[j] = ok ? ldg4(p.A2 + (size_t)row * p.lda2 + k) : zero4();
+      r[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA, voA[j] + so, 0, 0));
+      if (PRO == PRO_BNBWD)
+        r2[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA2, voA2[j] + so, 0, 0));
     }
   };
-  auto store_tile = [&](int kt, char* st) {
+  auto store_tile = [&](int kt, char* st, const float4 (&r_)[2], const float4 (&r2_)[2]) {
     const int k = kt * S3_BK + sc;
-    const bool kok = k < p.K;
+    const bool kok = k < p.K || PRO != PRO_NONE;   // coefficient image is zero beyond K
     float4 ka = zero4(), kb = zero4(), kc = zero4();
-    if (PRO != PRO_NONE && kok) {
-      ka = ldg4(p.pa + k);
-      kb = ldg4(p.pb + k);
-      if (PRO == PRO_BNBWD) kc = ldg4(p.pc + k);
+    if (PRO != PRO_NONE) {        // prologue coefficients from their LDS image (no vmcnt wait)
+      ka = *reinterpret_cast<const float4*>(coef + k);
+      kb = *reinterpret_cast<const float4*>(coef + KP + k);
+      if (PRO == PRO_BNBWD) kc = *reinterpret_cast<const float4*>(coef + 2 * KP + k);
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int r = sr + 128 * j;
-      const bool ok = kok && (m0 + r) < p.M;
-      const float4 v = ok ? pro_apply<PRO>(ra[j], ra2[j], ka, kb, kc) : zero4();
+      // rows beyond M need no mask: they only feed output rows the epilogue never stores or
+      // counts; k beyond K must be exact zeros (the W image is zero there, but 0*inf = nan)
+      float4 v = pro_apply<PRO>(r_[j], r2_[j], ka, kb, kc);
+      v.x = kok ? v.x : 0.f; v.y = kok ? v.y : 0.f; v.z = kok ? v.z : 0.f; v.w = kok ? v.w : 0.f;
       uint2 h, m, l;
       split2(v.x, v.y, h.x, m.x, l.x);
       split2(v.z, v.w, h.y, m.y, l.y);
@@ -205,22 +232,57 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
       *reinterpret_cast<uint2*>(q + 2 * S3_PLANE) = l;
     }
   };
-
-  dma_w(0, smem);
-  load_tile(0);
-  store_tile(0, smem);
-  __syncthreads();
-  for (int kt = 0; kt < KT; ++kt) {
+  // one k-tile: compute tile kt from its stage, convert tile kt+1 out of register set CS into
+  // the other stage, refill set CS^1 with tile kt+2.  Branch free (tail tiles load zeros).
+  auto iter = [&](int kt, auto cs) {
+    constexpr int CS = decltype(cs)::value;
     char* cur = smem + (kt & 1) * S3_STAGE;
     char* nxt = smem + ((kt + 1) & 1) * S3_STAGE;
-    if (kt + 1 < KT) {
-      dma_w(kt + 1, nxt);
-      load_tile(kt + 1);
-    }
+    dma_w(kt + 1, nxt);
+    load_tile(kt + 2, ra[CS ^ 1], ra2[CS ^ 1]);
+    // keep the memory operations at the head of the k-tile (the scheduler otherwise sinks
+    // them next to the barrier, whose vmcnt(0) then exposes their full latency)
+    __builtin_amdgcn_sched_barrier(0);
     s3_compute(acc, cur, wm, wn, l31, half);
-    if (kt + 1 < KT) store_tile(kt + 1, nxt);
+    store_tile(kt + 1, nxt, ra[CS], ra2[CS]);
+    // Interleave: the conversion VALU work of tile kt+1 is independent of the MFMAs of tile
+    // kt; in-order issue only overlaps them if they alternate in program order, so ask the
+    // scheduler for 1 MFMA : 3 VALU groups (MFMA issue occupies 8 of its 32 cycles).
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+    }
+    __syncthreads();
+  };
+
+  dma_w(0, smem);
+  load_tile(0, ra[0], ra2[0]);
+  load_tile(1, ra[1], ra2[1]);
+  if (PRO != PRO_NONE) {
+    // per-k prologue coefficient vectors -> LDS once per block, zero beyond K (which also
+    // zeroes the prologue output there: relu(a*0+0) = 0, 0*dy + 0*z + 0 = 0); two tiles of
+    // slack for the prefetch distance
+    for (int i = tid; i < KP; i += 512) {
+      const bool in = i < p.K;
+      coef[i] = in ? p.pa[i] : 0.f;
+      coef[KP + i] = in ? p.pb[i] : 0.f;
+      if (PRO == PRO_BNBWD) coef[2 * KP + i] = in ? p.pc[i] : 0.f;
+    }
     __syncthreads();
   }
+  store_tile(0, smem, ra[0], ra2[0]);
+  __syncthreads();
+  int kt = 0;
+  for (; kt + 1 < KT; kt += 2) {
+    iter(kt, std::integral_constant<int, 1>{});
+    iter(kt + 1, std::integral_constant<int, 0>{});
+  }
+  if (kt < KT) iter(kt, std::integral_constant<int, 1>{});
   nt_epilogue<EPI, 4, 2>(acc, p, m0 + wm, n0 + wn, tile_m * 2 + (wave >> 2), lane);
 }
 
@@ -259,9 +321,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_s3_kernel(const TNParams p) {
     qa = p.qa[n0 + c];
     qb = p.qb[n0 + c];
   }
-  const float* Ap = p.A + m0 + c;
-  const float* A2p = (PROA == PRO_BNBWD) ? p.A2 + m0 + c : nullptr;
-  const float* Bp = p.B + n0 + c;
 
   f32x16 acc[4][2];
 #pragma unroll
@@ -271,32 +330,52 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_s3_kernel(const TNParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float va[8], va2[8], vb[8];
+  float va[1][8], va2[1][8], vb[1][8];
   float csum = 0.f;
+  // Buffer descriptors over this split's rows, based at column m0 / n0: rows at or beyond
+  // p_end are out of range and read as 0 (no clamps, no exec-mask branches); per-lane byte
+  // offsets are 32-bit.
+  const int nrows = p_end - p_begin > 0 ? p_end - p_begin : 0;
+  int acols = p.Mo - m0; acols = acols > 256 ? 256 : acols;
+  int bcols = p.Ni - n0; bcols = bcols > 256 ? 256 : bcols;
+  const size_t abytes = nrows > 0 ? ((size_t)(nrows - 1) * p.lda + acols) * 4 : 0;
+  const size_t a2bytes = nrows > 0 ? ((size_t)(nrows - 1) * p.lda2 + acols) * 4 : 0;
+  const size_t bbytes = nrows > 0 ? ((size_t)(nrows - 1) * p.ldb + bcols) * 4 : 0;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.A + (size_t)p_begin * p.lda + m0), 0, (int)abytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((PROA == PRO_BNBWD ? p.A2 + (size_t)p_begin * p.lda2 + m0 : p.A)), 0,
+      (int)(PROA == PRO_BNBWD ? a2bytes : 0), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.B + (size_t)p_begin * p.ldb + n0), 0, (int)bbytes, 0x00020000);
+  const int voA = (oct * 8 * (int)p.lda + c) * 4, voA2 = (oct * 8 * (int)p.lda2 + c) * 4;
+  const int voB = (oct * 8 * (int)p.ldb + c) * 4;
+  const int stepA = (int)p.lda * 4, stepA2 = (int)p.lda2 * 4, stepB = (int)p.ldb * 4;
 
-  auto load_tile = [&](int kt) {
-    const int r0 = p_begin + kt * S3_BK + oct * 8;
+  auto load_tile = [&](int kt, float (&xa)[8], float (&xa2)[8], float (&xb)[8]) {
+    const int oa = voA + kt * S3_BK * stepA, oa2 = voA2 + kt * S3_BK * stepA2;
+    const int ob = voB + kt * S3_BK * stepB;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int row = r0 + j;
-      const bool rok = row < p_end;
-      va[j] = (rok && aok) ? Ap[(size_t)row * p.lda] : 0.f;
-      if (PROA == PRO_BNBWD) va2[j] = (rok && aok) ? A2p[(size_t)row * p.lda2] : 0.f;
-      vb[j] = (rok && bok) ? Bp[(size_t)row * p.ldb] : 0.f;
+      xa[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsA, oa + j * stepA, 0, 0));
+      if (PROA == PRO_BNBWD)
+        xa2[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsA2, oa2 + j * stepA2, 0, 0));
+      xb[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, ob + j * stepB, 0, 0));
     }
   };
-  auto store_tile = [&](int kt, char* st) {
+  auto store_tile = [&](int kt, char* st, const float (&xa)[8], const float (&xa2)[8],
+                        const float (&xb)[8]) {
     const int r0 = p_begin + kt * S3_BK + oct * 8;
     float ta[8], tb[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const bool rok = (r0 + j) < p_end;
-      float x = va[j];
-      if (PROA == PRO_BNBWD) x = fmaf(ka, va[j], fmaf(kb, va2[j], kc));
-      else if (PROA == PRO_BNRELU) x = fmaxf(fmaf(va[j], ka, kb), 0.f);
+      float x = xa[j];
+      if (PROA == PRO_BNBWD) x = fmaf(ka, xa[j], fmaf(kb, xa2[j], kc));
+      else if (PROA == PRO_BNRELU) x = fmaxf(fmaf(xa[j], ka, kb), 0.f);
       ta[j] = (rok && aok) ? x : 0.f;
-      float y = vb[j];
-      if (PROB == PRO_BNRELU) y = fmaxf(fmaf(vb[j], qa, qb), 0.f);
+      float y = xb[j];
+      if (PROB == PRO_BNRELU) y = fmaxf(fmaf(xb[j], qa, qb), 0.f);
       tb[j] = (rok && bok) ? y : 0.f;
       csum += ta[j];
     }
@@ -318,18 +397,21 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_s3_kernel(const TNParams p) {
     *reinterpret_cast<uint4*>(q + S3_PLANE) = m;
     *reinterpret_cast<uint4*>(q + 2 * S3_PLANE) = l;
   };
-
+  // distance-1 software pipeline (a second staging register set does not fit next to the
+  // 128 accumulators): loads of tile kt+1 are issued ahead of the MFMAs of tile kt and
+  // converted after them.
   if (KT > 0) {
-    load_tile(0);
-    store_tile(0, smem);
+    load_tile(0, va[0], va2[0], vb[0]);
+    store_tile(0, smem, va[0], va2[0], vb[0]);
   }
   __syncthreads();
   for (int kt = 0; kt < KT; ++kt) {
     char* cur = smem + (kt & 1) * S3_STAGE;
     char* nxt = smem + ((kt + 1) & 1) * S3_STAGE;
-    if (kt + 1 < KT) load_tile(kt + 1);
+    load_tile(kt + 1, va[0], va2[0], vb[0]);       // past the last tile: out of range -> zeros
+    __builtin_amdgcn_sched_barrier(0);
     s3_compute(acc, cur, wm, wn, l31, half);
-    if (kt + 1 < KT) store_tile(kt + 1, nxt);
+    store_tile(kt + 1, nxt, va[0], va2[0], vb[0]);
     __syncthreads();
   }
 

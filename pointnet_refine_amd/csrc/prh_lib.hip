@@ -99,7 +99,9 @@ inline bool split_enabled() {
   }
   return g_gemm_mode != 0;
 }
-inline bool nt_use_s3(int M, int N, int K) { return split_enabled() && K >= 64 && N >= 128 && M >= 512; }
+inline bool nt_use_s3(int M, int N, int K) {
+  return split_enabled() && K >= 64 && K <= 4096 && N >= 128 && M >= 512;   // K cap: coefficient LDS
+}
 inline bool tn_use_s3(int P, int Mo, int Ni) { return split_enabled() && Mo >= 128 && Ni >= 64 && P >= 2048; }
 
 // Statistics partials: `count` tiles of `rows` rows each
@@ -109,8 +111,13 @@ inline int stat_tiles_max(int P) { return 2 * cdiv(P, BM); }   // largest count 
 template <typename K>
 int allow_big_lds(K kernel) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, S3_LDS));
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   return PRH_OK;
+}
+// dynamic LDS of the NT split core: two stages + the prologue coefficient vectors
+inline size_t nt_s3_lds(int K, int pro) {
+  const int KP = (cdiv(K, S3_BK) + 2) * S3_BK;
+  return (size_t)S3_LDS + (pro == PRO_NONE ? 0 : (pro == PRO_BNBWD ? 3 : 2) * (size_t)KP * 4);
 }
 
 // ------------------------------------------------------------------ launch helpers
@@ -139,8 +146,8 @@ int launch_nt(NTParams p, hipStream_t st, StatInfo* si = nullptr) {
       if (attr_rc != PRH_OK) return attr_rc;
       snprintf(nm, sizeof(nm), "gemm_nt_s3<%d,%d> K=%d N=%d", PRO, EPI, p.K, p.N);
       ProfScope ps(nm, 2.0 * p.M * (double)p.N * p.K, by, st);
-      hipLaunchKernelGGL((gemm_nt_s3_kernel<PRO, EPI>), dim3((unsigned)tiles), dim3(512), S3_LDS, st,
-                         p, (const char*)p.wprep);
+      hipLaunchKernelGGL((gemm_nt_s3_kernel<PRO, EPI>), dim3((unsigned)tiles), dim3(512),
+                         nt_s3_lds(p.K, PRO), st, p, (const char*)p.wprep);
       LAUNCH_CHECK();
       if (si) { si->count = 2 * cdiv(p.M, S3_BM); si->rows = 128; }
       return PRH_OK;
