@@ -133,6 +133,29 @@ class DetrTransformerDecoderLayer(nn.Module):
         tgt = self.norm3(tgt + self.dropout3(tgt2))
         return tgt
 
+    def forward_projected(self, tgt, k_proj, v_proj, query_pos=None):
+        """Same layer with the cross-attention key/value projections already applied
+        (k_proj = (memory+pos) Wk^T + bk, v_proj = memory Wv^T + bv, each (B,N,C), possibly a
+        strided column block).  nn.MultiheadAttention's semantics written out: 8 heads of 32
+        contiguous channels, scale 1/sqrt(32), dropout on the attention weights."""
+        q = k = self.with_pos_embed(tgt, query_pos)
+        tgt2 = self.self_attn(q, k, value=tgt, need_weights=False)[0]
+        tgt = self.norm1(tgt + self.dropout1(tgt2))
+        ca = self.cross_attn
+        d, h = ca.embed_dim, ca.num_heads
+        B, M, _ = tgt.shape
+        N = k_proj.shape[1]
+        qp = F.linear(self.with_pos_embed(tgt, query_pos), ca.in_proj_weight[:d], ca.in_proj_bias[:d])
+        qh = qp.view(B, M, h, d // h).transpose(1, 2)
+        kh = k_proj.view(B, N, h, d // h).transpose(1, 2)
+        vh = v_proj.view(B, N, h, d // h).transpose(1, 2)
+        o = F.scaled_dot_product_attention(qh, kh, vh, dropout_p=ca.dropout if self.training else 0.0)
+        tgt2 = ca.out_proj(o.transpose(1, 2).reshape(B, M, d))
+        tgt = self.norm2(tgt + self.dropout2(tgt2))
+        tgt2 = self.linear2(self.dropout(self.activation(self.linear1(tgt))))
+        tgt = self.norm3(tgt + self.dropout3(tgt2))
+        return tgt
+
 
 class LineRefineNet(nn.Module):
     """Reference: src/model.py:137-234.  forward(context (B,N,4), noisy_line (B,M,3)) ->
@@ -179,13 +202,30 @@ class LineRefineNet(nn.Module):
 
     def decode(self, context, noisy_line, memory, tgt):
         """Iterative refinement (src/model.py:197-234) given memory (B,N,256) and the initial
-        queries tgt (B,M,256).  No BatchNorm in here, so it may be run on batch chunks."""
+        queries tgt (B,M,256).  No BatchNorm in here, so it may be run on batch chunks.
+
+        Same arithmetic as the reference's decoder layers, reorganised around what is constant
+        over the six layers: `memory` and `pos_mem` do not change, so the cross-attention key
+        and value projections of ALL layers (src/model.py:123-126: k = memory+pos, v = memory,
+        packed in_proj rows [256:512] and [512:768]) are two GEMMs of width 6*256 on the HIP
+        GEMM cores instead of twelve library GEMMs plus six elementwise adds."""
         pos_mem = self.pos_emb(context[:, :, :3])                   # (B, N, 256)
+        d = self.d_model
+        layers = self.decoder_layers
+        mempos = memory + pos_mem
+        wk = torch.cat([l.cross_attn.in_proj_weight[d:2 * d] for l in layers])
+        bk = torch.cat([l.cross_attn.in_proj_bias[d:2 * d] for l in layers])
+        wv = torch.cat([l.cross_attn.in_proj_weight[2 * d:] for l in layers])
+        bv = torch.cat([l.cross_attn.in_proj_bias[2 * d:] for l in layers])
+        # split (not slicing): its backward is one concatenation instead of six zero-filled
+        # full-size gradient buffers that autograd then adds up
+        k_all = ops.linear(mempos, wk, bk).split(d, dim=-1)         # 6 x (B, N, 256) views
+        v_all = ops.linear(memory, wv, bv).split(d, dim=-1)
         current_line_coords = noisy_line.clone()
         all_pred_offsets = []
-        for decoder_layer, reg_branch in zip(self.decoder_layers, self.reg_branches):
+        for i, (decoder_layer, reg_branch) in enumerate(zip(layers, self.reg_branches)):
             pos_tgt = self.pos_emb(current_line_coords)
-            tgt = decoder_layer(tgt, memory, query_pos=pos_tgt, pos=pos_mem)
+            tgt = decoder_layer.forward_projected(tgt, k_all[i], v_all[i], query_pos=pos_tgt)
             delta_offset = reg_branch(tgt)
             current_line_coords = current_line_coords + delta_offset      # no detach (H5)
             all_pred_offsets.append(current_line_coords - noisy_line)
