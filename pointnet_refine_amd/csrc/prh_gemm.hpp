@@ -208,6 +208,121 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[MT][NT], const NTParam
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Vectorised epilogue for wave tiles of NT = 2 MFMA blocks (64 columns): the accumulator
+// layout puts one COLUMN on a lane, so direct stores are 4 B per lane to two 128-B row
+// segments per instruction.  Here each 32 x 64 block of the wave tile goes through a
+// wave-private LDS scratch (row stride 68 floats) and comes back row-major, 16 B per lane,
+// four full 256-B row segments per instruction: 4x fewer memory instructions for the
+// store and for every epilogue operand read (z for the ReLU mask, the old gradient).
+// `scratch` = this wave's 32*68 floats.  Requires N, ldc, lde1 multiples of 4.
+// ---------------------------------------------------------------------------------------
+constexpr int EPI_LDW = 68;
+
+template <int EPI, int MT>
+__device__ __forceinline__ void nt_epilogue_vec(f32x16 (&acc)[MT][2], const NTParams& p, int rbase_,
+                                                int cbase, int rb, int lane, float* scratch) {
+  const int half = lane >> 5, l31 = lane & 31;
+  const int rbase = __builtin_amdgcn_readfirstlane(rbase_);
+  float* __restrict__ Cb = p.C + (size_t)rbase * p.ldc;
+  const float* __restrict__ Eb = p.E1 != nullptr ? p.E1 + (size_t)rbase * p.lde1 : nullptr;
+  const int ldc = (int)p.ldc, lde1 = (int)p.lde1;
+  const int mrows = p.M - rbase;
+  const int rr = lane >> 4, c4 = (lane & 15) * 4;     // row-major phase: 4 rows x 16 float4
+  const int col4 = cbase + c4;
+  const bool c4ok = col4 < p.N;
+  float4 bias4 = zero4(), es4 = zero4(), et4 = zero4();
+  if (c4ok) {
+    if (p.bias != nullptr) bias4 = ldg4(p.bias + col4);
+    if (EPI == EPI_DGRAD && (p.flags & F_MASK) != 0) { es4 = ldg4(p.es + col4); et4 = ldg4(p.et + col4); }
+  }
+
+  if (EPI == EPI_BIAS_STATS) {
+    // statistics straight from the accumulators (column on the lane): sum, then centred M2
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int col = cbase + nt * 32 + l31;
+      const bool cok = col < p.N;
+      const float bias = (p.bias != nullptr && cok) ? p.bias[col] : 0.f;
+      float s = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (mt * 32 + crow(r, half) < mrows) s += acc[mt][nt][r] + bias;
+      s += __shfl_xor(s, 32);
+      const int nrows = mrows < 0 ? 0 : (mrows > MT * 32 ? MT * 32 : mrows);
+      const float mean = nrows > 0 ? s / (float)nrows : 0.f;
+      float m2 = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float dlt = acc[mt][nt][r] + bias - mean;
+          if (mt * 32 + crow(r, half) < mrows) m2 = fmaf(dlt, dlt, m2);
+        }
+      m2 += __shfl_xor(m2, 32);
+      if (half == 0 && cok) {
+        p.ws_a[(size_t)rb * p.N + col] = s;
+        p.ws_b[(size_t)rb * p.N + col] = m2;
+      }
+    }
+  }
+
+  const bool mask = (p.flags & F_MASK) != 0, accum = (p.flags & F_ACCUM) != 0;
+  const bool need_z = EPI == EPI_DGRAD && (mask || (p.flags & F_STATS) != 0);
+  float4 s1 = zero4(), s2 = zero4();
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    // accumulator block -> scratch (column layout: conflict-free 128-B rows)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) scratch[crow(r, half) * EPI_LDW + nt * 32 + l31] = acc[mt][nt][r];
+    // scratch -> row-major float4 per lane
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int lrow = it * 4 + rr;
+      const int lr = mt * 32 + lrow;
+      float4 v = *reinterpret_cast<const float4*>(scratch + lrow * EPI_LDW + c4);
+      if (lr < mrows && c4ok) {
+        v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+        if (EPI == EPI_DGRAD) {
+          if (accum) {
+            const float4 o = ldg4(Cb + lr * ldc + col4);
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+          }
+          float4 z = zero4();
+          if (need_z) z = ldg4(Eb + lr * lde1 + col4);
+          if (mask) {
+            v.x = fmaf(z.x, es4.x, et4.x) > 0.f ? v.x : 0.f;
+            v.y = fmaf(z.y, es4.y, et4.y) > 0.f ? v.y : 0.f;
+            v.z = fmaf(z.z, es4.z, et4.z) > 0.f ? v.z : 0.f;
+            v.w = fmaf(z.w, es4.w, et4.w) > 0.f ? v.w : 0.f;
+          }
+          s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+          s2.x = fmaf(v.x, z.x, s2.x); s2.y = fmaf(v.y, z.y, s2.y);
+          s2.z = fmaf(v.z, z.z, s2.z); s2.w = fmaf(v.w, z.w, s2.w);
+        } else if ((p.flags & F_RELU_OUT) != 0) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        *reinterpret_cast<float4*>(Cb + lr * ldc + col4) = v;
+      }
+    }
+  }
+  if (EPI == EPI_DGRAD && (p.flags & F_STATS) != 0) {
+    // column sums: reduce over the 4 row groups (lane bits 4,5)
+    s1.x += __shfl_xor(s1.x, 16); s1.y += __shfl_xor(s1.y, 16); s1.z += __shfl_xor(s1.z, 16); s1.w += __shfl_xor(s1.w, 16);
+    s2.x += __shfl_xor(s2.x, 16); s2.y += __shfl_xor(s2.y, 16); s2.z += __shfl_xor(s2.z, 16); s2.w += __shfl_xor(s2.w, 16);
+    s1.x += __shfl_xor(s1.x, 32); s1.y += __shfl_xor(s1.y, 32); s1.z += __shfl_xor(s1.z, 32); s1.w += __shfl_xor(s1.w, 32);
+    s2.x += __shfl_xor(s2.x, 32); s2.y += __shfl_xor(s2.y, 32); s2.z += __shfl_xor(s2.z, 32); s2.w += __shfl_xor(s2.w, 32);
+    if (lane < 16 && c4ok) {
+      *reinterpret_cast<float4*>(p.ws_a + (size_t)rb * p.N + col4) = s1;
+      *reinterpret_cast<float4*>(p.ws_b + (size_t)rb * p.N + col4) = s2;
+    }
+  }
+}
+
 template <int PRO, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NTParams p) {
   __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * BK];

@@ -283,7 +283,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
     iter(kt + 1, std::integral_constant<int, 0>{});
   }
   if (kt < KT) iter(kt, std::integral_constant<int, 1>{});
-  nt_epilogue<EPI, 4, 2>(acc, p, m0 + wm, n0 + wn, tile_m * 2 + (wave >> 2), lane);
+  // the stage buffers are free now (the loop ended on a barrier with every DMA drained):
+  // use them as wave-private scratch for the row-major, 16-B-per-lane epilogue
+  const bool vec_ok = ((p.N | (int)p.ldc) & 3) == 0 && (p.E1 == nullptr || ((int)p.lde1 & 3) == 0) &&
+                      (p.flags & F_E1_ROWVEC) == 0;
+  if (vec_ok)
+    nt_epilogue_vec<EPI, 4>(acc, p, m0 + wm, n0 + wn, tile_m * 2 + (wave >> 2), lane,
+                            reinterpret_cast<float*>(smem) + wave * (32 * EPI_LDW));
+  else
+    nt_epilogue<EPI, 4, 2>(acc, p, m0 + wm, n0 + wn, tile_m * 2 + (wave >> 2), lane);
 }
 
 // ---------------------------------------------------------------------------------------
