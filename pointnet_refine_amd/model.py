@@ -31,6 +31,15 @@ def _bn_buffers(bn: nn.BatchNorm1d):
     return [bn.running_mean, bn.running_var, bn.num_batches_tracked]
 
 
+def _lin(x, weight, bias):
+    """nn.Linear arithmetic on the HIP GEMM cores when the shapes fit them (in/out features
+    multiples of 4, GPU fp32); the 3-wide layers (pos_emb input, regression output) stay on
+    torch.nn.functional.linear."""
+    if x.is_cuda and weight.shape[0] % 4 == 0 and weight.shape[1] % 4 == 0:
+        return ops.linear(x, weight, bias)
+    return F.linear(x, weight, bias)
+
+
 class MultiScalePointNetEncoder(nn.Module):
     """Multi-scale PointNet encoder with dual pooling (reference: src/model.py:5-62)."""
 
@@ -138,21 +147,29 @@ class DetrTransformerDecoderLayer(nn.Module):
         (k_proj = (memory+pos) Wk^T + bk, v_proj = memory Wv^T + bv, each (B,N,C), possibly a
         strided column block).  nn.MultiheadAttention's semantics written out: 8 heads of 32
         contiguous channels, scale 1/sqrt(32), dropout on the attention weights."""
-        q = k = self.with_pos_embed(tgt, query_pos)
-        tgt2 = self.self_attn(q, k, value=tgt, need_weights=False)[0]
+        sa = self.self_attn
+        d, h = sa.embed_dim, sa.num_heads
+        B, M, _ = tgt.shape
+        qk_in = self.with_pos_embed(tgt, query_pos)
+        qk = _lin(qk_in, sa.in_proj_weight[:2 * d], sa.in_proj_bias[:2 * d])      # q and k share the input
+        vv = _lin(tgt, sa.in_proj_weight[2 * d:], sa.in_proj_bias[2 * d:])
+        qh = qk[..., :d].reshape(B, M, h, d // h).transpose(1, 2)
+        kh = qk[..., d:].reshape(B, M, h, d // h).transpose(1, 2)
+        vh = vv.view(B, M, h, d // h).transpose(1, 2)
+        o = F.scaled_dot_product_attention(qh, kh, vh, dropout_p=sa.dropout if self.training else 0.0)
+        tgt2 = _lin(o.transpose(1, 2).reshape(B, M, d), sa.out_proj.weight, sa.out_proj.bias)
         tgt = self.norm1(tgt + self.dropout1(tgt2))
         ca = self.cross_attn
-        d, h = ca.embed_dim, ca.num_heads
-        B, M, _ = tgt.shape
         N = k_proj.shape[1]
-        qp = F.linear(self.with_pos_embed(tgt, query_pos), ca.in_proj_weight[:d], ca.in_proj_bias[:d])
+        qp = _lin(self.with_pos_embed(tgt, query_pos), ca.in_proj_weight[:d], ca.in_proj_bias[:d])
         qh = qp.view(B, M, h, d // h).transpose(1, 2)
         kh = k_proj.view(B, N, h, d // h).transpose(1, 2)
         vh = v_proj.view(B, N, h, d // h).transpose(1, 2)
         o = F.scaled_dot_product_attention(qh, kh, vh, dropout_p=ca.dropout if self.training else 0.0)
-        tgt2 = ca.out_proj(o.transpose(1, 2).reshape(B, M, d))
+        tgt2 = _lin(o.transpose(1, 2).reshape(B, M, d), ca.out_proj.weight, ca.out_proj.bias)
         tgt = self.norm2(tgt + self.dropout2(tgt2))
-        tgt2 = self.linear2(self.dropout(self.activation(self.linear1(tgt))))
+        hid = self.activation(_lin(tgt, self.linear1.weight, self.linear1.bias))
+        tgt2 = _lin(self.dropout(hid), self.linear2.weight, self.linear2.bias)
         tgt = self.norm3(tgt + self.dropout3(tgt2))
         return tgt
 
