@@ -112,3 +112,46 @@ def test_full_size_properties():
     with torch.no_grad():
         o = O.linerefine_forward(O.as_params(sd), ctx[100:102].cpu(), noisy[100:102].cpu())
     assert maxdiff(out[:, 100:102], o) < 1e-4
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["fp32-cores", "split-cores"])
+def test_g1_g2_on_both_gemm_cores(golden_dir, mode):
+    """The golden vectors hold on the exact fp32 MFMA cores and on the split-bf16 cores."""
+    from pointnet_refine_amd import _lib
+    lib = _lib.lib()
+    old = lib.prh_get_gemm_mode()
+    lib.prh_set_gemm_mode(mode)
+    try:
+        g = np.load(os.path.join(golden_dir, "g1_eval_forward.npz"))
+        sd = P.linerefine_state_dict(0)
+        m = _model(sd).eval()
+        ctx, noisy, target = P.synth_batch(8, 256, 4, 32, seed=1234)
+        with torch.no_grad():
+            out = m(ctx.cuda(), noisy.cuda())
+        assert maxdiff(out, g["out"]) < 1e-4
+        g2 = np.load(os.path.join(golden_dir, "g2_train_fwd_bwd.npz"))
+        m = _model(sd).train()
+        _zero_dropout(m)
+        out = m(ctx.cuda(), noisy.cuda())
+        loss = sum(torch.nn.functional.l1_loss(out[l], target.cuda()) for l in range(6)) / 6
+        loss.backward()
+        assert maxdiff(out, g2["out"]) < 2e-4
+        k = "context_encoder.fusion.0.weight"
+        gr = dict(m.named_parameters())[k].grad.reshape(-1).double()
+        nrm = float(g2["grad_norms"][list(g2["grad_keys"]).index(k)])
+        assert abs(float(gr.norm()) - nrm) <= 5e-3 * nrm
+    finally:
+        lib.prh_set_gemm_mode(old)
+
+
+def test_batch_4096_points_2048_shapes_run():
+    """BASELINE config 4 shape per rank scaled to what one test may hold (B=64, N=2048):
+    eval forward agrees with the oracle on a slice."""
+    sd = P.linerefine_state_dict(0)
+    m = _model(sd).eval()
+    ctx, noisy, _ = P.synth_batch(64, 2048, 4, 32, seed=5)
+    with torch.no_grad():
+        out = m(ctx.cuda(), noisy.cuda())
+        o = O.linerefine_forward(O.as_params(sd), ctx[10:12], noisy[10:12])
+    assert out.shape == (6, 64, 32, 3)
+    assert maxdiff(out[:, 10:12], o) < 1e-4
