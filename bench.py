@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4096, help="segments per GPU per step")
     ap.add_argument("--points", type=int, default=1024, help="context points per segment")
-    ap.add_argument("--decoder-chunk", type=int, default=512,
+    ap.add_argument("--decoder-chunk", type=int, default=2048,
                     help="segments per decoder micro-batch (bounds the stock-PyTorch decoder's "
                          "activation memory; results are identical to the unchunked step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

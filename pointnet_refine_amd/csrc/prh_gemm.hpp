@@ -234,8 +234,13 @@ __device__ __forceinline__ void nt_epilogue_vec(f32x16 (&acc)[MT][2], const NTPa
   float4 bias4 = zero4(), es4 = zero4(), et4 = zero4();
   if (c4ok) {
     if (p.bias != nullptr) bias4 = ldg4(p.bias + col4);
-    if (EPI == EPI_DGRAD && (p.flags & F_MASK) != 0) { es4 = ldg4(p.es + col4); et4 = ldg4(p.et + col4); }
+    if ((EPI == EPI_DGRAD && (p.flags & F_MASK) != 0) || EPI == EPI_GATE) {
+      es4 = ldg4(p.es + col4);
+      et4 = ldg4(p.et + col4);
+    }
   }
+  float* __restrict__ C2b = (EPI == EPI_GATE && p.C2 != nullptr) ? p.C2 + (size_t)rbase * p.ldc2 : nullptr;
+  const int ldc2 = (int)p.ldc2;
 
   if (EPI == EPI_BIAS_STATS) {
     // statistics straight from the accumulators (column on the lane): sum, then centred M2
@@ -303,6 +308,15 @@ __device__ __forceinline__ void nt_epilogue_vec(f32x16 (&acc)[MT][2], const NTPa
           s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
           s2.x = fmaf(v.x, z.x, s2.x); s2.y = fmaf(v.y, z.y, s2.y);
           s2.z = fmaf(v.z, z.z, s2.z); s2.w = fmaf(v.w, z.w, s2.w);
+        } else if (EPI == EPI_GATE) {
+          // F = relu(zf*s+t) * m,  m = 0.5 + 0.5*sigmoid(acc + b)     (src/model.py:51,54-55)
+          const float4 zf = ldg4(Eb + lr * lde1 + col4);
+          float4 m;
+          m.x = 0.5f + 0.5f / (1.f + __expf(-v.x)); m.y = 0.5f + 0.5f / (1.f + __expf(-v.y));
+          m.z = 0.5f + 0.5f / (1.f + __expf(-v.z)); m.w = 0.5f + 0.5f / (1.f + __expf(-v.w));
+          v.x = fmaxf(fmaf(zf.x, es4.x, et4.x), 0.f) * m.x; v.y = fmaxf(fmaf(zf.y, es4.y, et4.y), 0.f) * m.y;
+          v.z = fmaxf(fmaf(zf.z, es4.z, et4.z), 0.f) * m.z; v.w = fmaxf(fmaf(zf.w, es4.w, et4.w), 0.f) * m.w;
+          if ((p.flags & F_STORE_GATE) != 0) *reinterpret_cast<float4*>(C2b + lr * ldc2 + col4) = m;
         } else if ((p.flags & F_RELU_OUT) != 0) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }

@@ -188,18 +188,25 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
   // extent = up to column K of the last row (A may be a column slice of a wider tensor, so
   // "arows * lda" would reach past the end of the allocation on the last row)
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.A + (size_t)m0 * p.lda), 0, (int)(((size_t)(arows - 1) * p.lda + p.K) * 4), 0x00020000);
+      (void*)(p.A + (size_t)m0 * p.lda), 0,
+      PRO == PRO_GATE1 ? 0 : (int)(((size_t)(arows - 1) * p.lda + p.K) * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc(
       (void*)((PRO == PRO_BNBWD ? p.A2 : p.A) + (size_t)m0 * (PRO == PRO_BNBWD ? p.lda2 : p.lda)), 0,
       (int)(((size_t)(arows - 1) * (PRO == PRO_BNBWD ? p.lda2 : p.lda) + p.K) * 4), 0x00020000);
   int voA[2], voA2[2];
+  float gi[2] = {0.f, 0.f};          // PRO_GATE1: the row's intensity (A has one value per row)
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     voA[j] = ((sr + 128 * j) * (int)p.lda + sc) * 4;
     voA2[j] = ((sr + 128 * j) * (int)p.lda2 + sc) * 4;
+    if (PRO == PRO_GATE1) {
+      const int row = m0 + sr + 128 * j;
+      gi[j] = row < p.M ? p.A[(size_t)row * p.lda] : 0.f;
+    }
   }
   auto load_tile = [&](int kt, float4 (&r)[2], float4 (&r2)[2]) {
     const int so = kt * (S3_BK * 4);
+    if (PRO == PRO_GATE1) return;     // operand is generated from gi[], nothing to load
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       r[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA, voA[j] + so, 0, 0));
@@ -221,7 +228,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
       const int r = sr + 128 * j;
       // rows beyond M need no mask: they only feed output rows the epilogue never stores or
       // counts; k beyond K must be exact zeros (the W image is zero there, but 0*inf = nan)
-      float4 v = pro_apply<PRO>(r_[j], r2_[j], ka, kb, kc);
+      float4 v;
+      if (PRO == PRO_GATE1) v = pro_apply<PRO>(make_float4(gi[j], 0.f, 0.f, 0.f), zero4(), ka, kb, kc);
+      else v = pro_apply<PRO>(r_[j], r2_[j], ka, kb, kc);
       v.x = kok ? v.x : 0.f; v.y = kok ? v.y : 0.f; v.z = kok ? v.z : 0.f; v.w = kok ? v.w : 0.f;
       uint2 h, m, l;
       split2(v.x, v.y, h.x, m.x, l.x);
@@ -286,7 +295,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
   // the stage buffers are free now (the loop ended on a barrier with every DMA drained):
   // use them as wave-private scratch for the row-major, 16-B-per-lane epilogue
   const bool vec_ok = ((p.N | (int)p.ldc) & 3) == 0 && (p.E1 == nullptr || ((int)p.lde1 & 3) == 0) &&
-                      (p.flags & F_E1_ROWVEC) == 0;
+                      (p.flags & F_E1_ROWVEC) == 0 && (p.C2 == nullptr || ((int)p.ldc2 & 3) == 0);
   if (vec_ok)
     nt_epilogue_vec<EPI, 4>(acc, p, m0 + wm, n0 + wn, tile_m * 2 + (wave >> 2), lane,
                             reinterpret_cast<float*>(smem) + wave * (32 * EPI_LDW));

@@ -119,6 +119,7 @@ inline size_t nt_s3_lds(int K, int pro) {
   const int KP = (cdiv(K, S3_BK) + 2) * S3_BK;
   return (size_t)S3_LDS + (pro == PRO_NONE ? 0 : (pro == PRO_BNBWD ? 3 : 2) * (size_t)KP * 4);
 }
+static_assert(8 * 32 * EPI_LDW * 4 <= S3_LDS, "epilogue scratch must fit in the stage buffers");
 
 // ------------------------------------------------------------------ launch helpers
 template <int PRO, int EPI>
@@ -133,8 +134,9 @@ int launch_nt(NTParams p, hipStream_t st, StatInfo* si = nullptr) {
   const double by = 4.0 * ((double)p.M * p.K * (PRO == PRO_BNBWD ? 2 : (PRO == PRO_GATE1 ? 0 : 1)) +
                            (double)p.M * p.N * (EPI == EPI_GATE ? 3 : (EPI == EPI_DGRAD ? 2 : 1)) +
                            (double)p.N * p.K);
-  if constexpr (PRO != PRO_GATE1 && EPI != EPI_GATE) {
-    if (p.wprep != nullptr && nt_use_s3(p.M, p.N, p.K)) {
+  {
+    if (p.wprep != nullptr && nt_use_s3(p.M, p.N, p.K) && p.lda <= 65536 && p.lda2 <= 65536 &&
+        !(EPI == EPI_GATE && ((p.N | (int)p.ldc | (int)p.lde1 | (int)p.ldc2) & 3) != 0)) {
       const int KT = cdiv(p.K, S3_BK), NTl = cdiv(p.N, S3_BN);
       const long th = (long)NTl * 256 * KT * 2;
       hipLaunchKernelGGL(prep_weights_s3_kernel, dim3((unsigned)cdiv(th, 256)), dim3(256), 0, st,
@@ -163,6 +165,7 @@ int launch_nt(NTParams p, hipStream_t st, StatInfo* si = nullptr) {
   return PRH_OK;
 }
 
+constexpr int TN_S3_MAX_LD = 4096;   // widest operand row the split TN core accepts
 struct TNPlan { int tiles_m, tiles_n, splits, rows_per_split; bool s3; };
 inline TNPlan tn_plan(int P, int Mo, int Ni, bool allow_s3) {
   TNPlan pl;
@@ -179,6 +182,10 @@ inline TNPlan tn_plan(int P, int Mo, int Ni, bool allow_s3) {
   int rps = cdiv(P, s);
   rps = cdiv(rps, bk) * bk;
   if (rps < bk) rps = bk;
+  // the split core addresses a split's rows through 32-bit buffer offsets: keep
+  // rows_per_split * leading_dimension * 4 below 2^31 for any ld <= TN_S3_MAX_LD
+  const int cap = (int)((2147483647L / (4L * TN_S3_MAX_LD)) / bk * bk);
+  if (pl.s3 && rps > cap) rps = cap;
   pl.splits = cdiv(P, rps) < 1 ? 1 : cdiv(P, rps);
   pl.rows_per_split = rps;
   return pl;
@@ -197,7 +204,8 @@ template <int PROA, int PROB>
 int launch_tn(TNParams p, float* slab, float* colsum_slab, float* C, long ldc, float* colsum_out,
               hipStream_t st) {
   if (p.Mo <= 0 || p.Ni <= 0) return PRH_OK;
-  TNPlan pl = tn_plan(p.P, p.Mo, p.Ni, PROB != PRO_GATE1);
+  const bool ld_ok = p.lda <= TN_S3_MAX_LD && p.ldb <= TN_S3_MAX_LD && p.lda2 <= TN_S3_MAX_LD;
+  TNPlan pl = tn_plan(p.P, p.Mo, p.Ni, PROB != PRO_GATE1 && ld_ok);
   if (!pl.s3 && ((p.Mo & 3) || (p.Ni & 3) || (p.lda & 3) || (PROB != PRO_GATE1 && (p.ldb & 3))))
     return fail(PRH_ERR_ARG, "gemm_tn: Mo/Ni/lda/ldb must be multiples of 4 (Mo=%d Ni=%d)", p.Mo,
                 p.Ni);
@@ -718,6 +726,7 @@ int prh_encoder_forward(const prh_encoder_params* prm, const float* ctx, int B, 
     p.W = prm->gate_w2; p.ldw = 64; p.K = 64; p.M = P; p.N = od; p.bias = prm->gate_b2;
     p.E1 = sv->z_fus; p.lde1 = od; p.es = sv->bn_scale + cat; p.et = sv->bn_shift + cat;
     p.C = fused; p.ldc = od; p.C2 = sv->gate; p.ldc2 = od;
+    p.wprep = w.wprep;
     p.flags = sv->gate ? F_STORE_GATE : 0;
     TRY((launch_nt<PRO_GATE1, EPI_GATE>(p, st)));
   }
