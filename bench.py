@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--decoder-chunk", type=int, default=2048,
                     help="segments per decoder micro-batch (bounds the stock-PyTorch decoder's "
                          "activation memory; results are identical to the unchunked step)")
+    ap.add_argument("--gemm", choices=["split", "fp32", "bf16"], default="split",
+                    help="GEMM cores: split = 3xbf16-split MFMA with fp32-level error (default, the "
+                         "parity path); fp32 = exact fp32 MFMA; bf16 = reduced precision (config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16)
     return ap.parse_args()
@@ -111,6 +114,7 @@ def main():
     from pointnet_refine_amd.synth import synthetic_batch
     from pointnet_refine_amd.train_step import TrainStep
     lib = _lib.lib()
+    lib.prh_set_gemm_mode({"fp32": 0, "split": 1, "bf16": 2}[args.gemm])
 
     torch.manual_seed(0)
     model = LineRefineNet().to(dev).train()
@@ -166,11 +170,13 @@ def main():
     # kernel runs on: the exact fp32 MFMA pipe, or - for the split cores, which issue 6 bf16
     # MFMA products per fp32-accurate MAC - the dense bf16 MFMA peak divided by 6.
     split = "_s3" in dname
-    peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS if split else FP32_MFMA_PEAK_TFLOPS
+    one = "_b1" in dname
+    peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS if split else (BF16_MFMA_PEAK_TFLOPS if one else FP32_MFMA_PEAK_TFLOPS)
     roofline = {"bound": "mfma", "kernel": dname, "achieved": round(achieved, 2),
                 "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "peak_basis": ("2500 TF dense bf16 MFMA / 6 products per fp32-accurate MAC (3-plane bf16 split)"
-                               if split else "157.3 TF fp32 MFMA (v_mfma_f32_32x32x2_f32)"),
+                               if split else ("2500 TF dense bf16 MFMA" if one else
+                                              "157.3 TF fp32 MFMA (v_mfma_f32_32x32x2_f32)")),
                 "issued_mfma_tflops": round(achieved * (SPLIT_PRODUCTS if split else 1), 1),
                 "vs_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                 "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": cnt,
@@ -185,7 +191,8 @@ def main():
             "value": round(world * B * args.steps / dt, 2), "unit": "segments/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32 (large GEMMs: 3xbf16-split MFMA, fp32 accumulate)" if lib.prh_get_gemm_mode() else "f32",
+            "vs_baseline": None, "dtype": {0: "f32", 1: "f32 (large GEMMs: 3xbf16-split MFMA, fp32 accumulate)",
+                      2: "bf16 MFMA operands, fp32 accumulate and storage (reduced precision)"}[lib.prh_get_gemm_mode()],
             "data": "synthetic",
             "config": {"workload": f"LineRefineNet training step (fwd + deep-supervision L1 + bwd + Adam), "
                                    f"B={B}/GPU, N={N}, M=32, C=4, fp32",

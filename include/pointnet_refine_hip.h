@@ -146,7 +146,10 @@ int prh_mlp_stack_backward(const prh_bn_layer* layers, int n_layers, int relu_la
  * (v_mfma_f32_32x32x2_f32) everywhere; the default routes large GEMMs to the split-bf16
  * cores (three bf16 planes per fp32 operand, six v_mfma_f32_32x32x16_bf16 products,
  * fp32-level error).  Both are checked against the oracle at the same 1e-4 gate.
- * prh_set_gemm_mode(0 = fp32, 1 = split) overrides the environment at run time
+ * PRH_GEMM=bf16 / mode 2 is the opt-in REDUCED-PRECISION mode (BASELINE config 3): the same
+ * cores with plain bf16 operands, one MFMA product, fp32 accumulate and fp32 storage; its
+ * parity gate is 5e-2, not 1e-4.
+ * prh_set_gemm_mode(0 = fp32, 1 = split, 2 = bf16) overrides the environment at run time
  * (process-wide; set it before launching work, not concurrently with it). */
 int prh_set_gemm_mode(int mode);
 int prh_get_gemm_mode(void);

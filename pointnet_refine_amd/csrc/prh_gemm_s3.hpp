@@ -109,26 +109,45 @@ __device__ __forceinline__ void mfma6(f32x16& acc, const bf16x8& ah, const bf16x
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh, acc, 0, 0, 0);
 }
 
-// one k-tile of MFMAs for a wave tile of 128 x 64 out of the stage at `st`
+// one k-tile of MFMAs for a wave tile of 128 x 64 out of the stage at `st`.
+// NPL = 3: fp32-accurate six-product form; NPL = 1: plain bf16 operands (h plane only),
+// one product - the reduced-precision mode of BASELINE config 3.
+template <int NPL>
 __device__ __forceinline__ void s3_compute(f32x16 (&acc)[4][2], const char* st, int wm, int wn,
                                            int l31, int half) {
-  bf16x8 w[2][3];
+  bf16x8 w[2][NPL];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int row = wn + j * 32 + l31;
     const char* q = st + S3_OPER + s3_off(row, half * 8);
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) w[j][pl] = *reinterpret_cast<const bf16x8*>(q + pl * S3_PLANE);
+    for (int pl = 0; pl < NPL; ++pl) w[j][pl] = *reinterpret_cast<const bf16x8*>(q + pl * S3_PLANE);
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = wm + i * 32 + l31;
     const char* q = st + s3_off(row, half * 8);
-    bf16x8 a[3];
+    bf16x8 a[NPL];
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(q + pl * S3_PLANE);
+    for (int pl = 0; pl < NPL; ++pl) a[pl] = *reinterpret_cast<const bf16x8*>(q + pl * S3_PLANE);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) mfma6(acc[i][j], a[0], a[1], a[2], w[j][0], w[j][1], w[j][2]);
+    for (int j = 0; j < 2; ++j) {
+      if constexpr (NPL == 3) mfma6(acc[i][j], a[0], a[1], a[2], w[j][0], w[j][1], w[j][2]);
+      else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], w[j][0], acc[i][j], 0, 0, 0);
+    }
+  }
+}
+
+// NPL-plane variant of split2 for packing: only the planes that are used are produced
+template <int NPL>
+__device__ __forceinline__ void splitn(float a0, float a1, unsigned& h, unsigned& m, unsigned& l) {
+  if constexpr (NPL == 3) {
+    split2(a0, a1, h, m, l);
+  } else {
+    f32x2 v = {a0, a1};
+    bf16x2 hb = __builtin_convertvector(v, bf16x2);
+    h = *reinterpret_cast<unsigned*>(&hb);
+    m = 0; l = 0;
   }
 }
 
@@ -136,7 +155,7 @@ __device__ __forceinline__ void s3_compute(f32x16 (&acc)[4][2], const char* st, 
 // NT: C[M,N] = pro(A)[M,K] * W'[N,K]^T, W' pre-split (Wp).  Same prologues/epilogues as
 // gemm_nt_kernel (EPI_GATE excluded).
 // ---------------------------------------------------------------------------------------
-template <int PRO, int EPI>
+template <int PRO, int EPI, int NPL>
 __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
                                                             const char* __restrict__ Wp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -175,7 +194,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
   auto dma_w = [&](int kt, char* st) {
     const char* q = wsrc + (size_t)(kt < KT ? kt : KT - 1) * S3_OPER;   // tail: harmless re-copy
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+    for (int pl = 0; pl < NPL; ++pl)
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)(q + pl * S3_PLANE),
           (__attribute__((address_space(3))) void*)(st + wdst + pl * S3_PLANE), 16, 0, 0);
@@ -233,12 +252,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
       else v = pro_apply<PRO>(r_[j], r2_[j], ka, kb, kc);
       v.x = kok ? v.x : 0.f; v.y = kok ? v.y : 0.f; v.z = kok ? v.z : 0.f; v.w = kok ? v.w : 0.f;
       uint2 h, m, l;
-      split2(v.x, v.y, h.x, m.x, l.x);
-      split2(v.z, v.w, h.y, m.y, l.y);
+      splitn<NPL>(v.x, v.y, h.x, m.x, l.x);
+      splitn<NPL>(v.z, v.w, h.y, m.y, l.y);
       char* q = st + s3_off(r, sc);
       *reinterpret_cast<uint2*>(q) = h;
-      *reinterpret_cast<uint2*>(q + S3_PLANE) = m;
-      *reinterpret_cast<uint2*>(q + 2 * S3_PLANE) = l;
+      if (NPL == 3) {
+        *reinterpret_cast<uint2*>(q + S3_PLANE) = m;
+        *reinterpret_cast<uint2*>(q + 2 * S3_PLANE) = l;
+      }
     }
   };
   // one k-tile: compute tile kt from its stage, convert tile kt+1 out of register set CS into
@@ -252,19 +273,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
     // keep the memory operations at the head of the k-tile (the scheduler otherwise sinks
     // them next to the barrier, whose vmcnt(0) then exposes their full latency)
     __builtin_amdgcn_sched_barrier(0);
-    s3_compute(acc, cur, wm, wn, l31, half);
+    s3_compute<NPL>(acc, cur, wm, wn, l31, half);
     store_tile(kt + 1, nxt, ra[CS], ra2[CS]);
     // Interleave: the conversion VALU work of tile kt+1 is independent of the MFMAs of tile
     // kt; in-order issue only overlaps them if they alternate in program order, so ask the
     // scheduler for 1 MFMA : 3 VALU groups (MFMA issue occupies 8 of its 32 cycles).
+    if constexpr (NPL == 3) {
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      for (int g = 0; g < 16; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      }
     }
     __syncthreads();
   };
@@ -310,7 +333,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
 // 8 values become one 16-B bf16 fragment per plane in the same [row = column][16 k] image
 // the NT kernel uses, so the MFMA loop is shared.
 // ---------------------------------------------------------------------------------------
-template <int PROA, int PROB>
+template <int PROA, int PROB, int NPL>
 __global__ __launch_bounds__(512, 2) void gemm_tn_s3_kernel(const TNParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -397,22 +420,26 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_s3_kernel(const TNParams p) {
       csum += ta[j];
     }
     uint4 h, m, l;
-    split2(ta[0], ta[1], h.x, m.x, l.x);
-    split2(ta[2], ta[3], h.y, m.y, l.y);
-    split2(ta[4], ta[5], h.z, m.z, l.z);
-    split2(ta[6], ta[7], h.w, m.w, l.w);
+    splitn<NPL>(ta[0], ta[1], h.x, m.x, l.x);
+    splitn<NPL>(ta[2], ta[3], h.y, m.y, l.y);
+    splitn<NPL>(ta[4], ta[5], h.z, m.z, l.z);
+    splitn<NPL>(ta[6], ta[7], h.w, m.w, l.w);
     char* q = st + s3_off(c, oct * 8);
     *reinterpret_cast<uint4*>(q) = h;
-    *reinterpret_cast<uint4*>(q + S3_PLANE) = m;
-    *reinterpret_cast<uint4*>(q + 2 * S3_PLANE) = l;
-    split2(tb[0], tb[1], h.x, m.x, l.x);
-    split2(tb[2], tb[3], h.y, m.y, l.y);
-    split2(tb[4], tb[5], h.z, m.z, l.z);
-    split2(tb[6], tb[7], h.w, m.w, l.w);
+    if (NPL == 3) {
+      *reinterpret_cast<uint4*>(q + S3_PLANE) = m;
+      *reinterpret_cast<uint4*>(q + 2 * S3_PLANE) = l;
+    }
+    splitn<NPL>(tb[0], tb[1], h.x, m.x, l.x);
+    splitn<NPL>(tb[2], tb[3], h.y, m.y, l.y);
+    splitn<NPL>(tb[4], tb[5], h.z, m.z, l.z);
+    splitn<NPL>(tb[6], tb[7], h.w, m.w, l.w);
     q += S3_OPER;
     *reinterpret_cast<uint4*>(q) = h;
-    *reinterpret_cast<uint4*>(q + S3_PLANE) = m;
-    *reinterpret_cast<uint4*>(q + 2 * S3_PLANE) = l;
+    if (NPL == 3) {
+      *reinterpret_cast<uint4*>(q + S3_PLANE) = m;
+      *reinterpret_cast<uint4*>(q + 2 * S3_PLANE) = l;
+    }
   };
   // distance-1 software pipeline (a second staging register set does not fit next to the
   // 128 accumulators): loads of tile kt+1 are issued ahead of the MFMAs of tile kt and
@@ -427,7 +454,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_s3_kernel(const TNParams p) {
     char* nxt = smem + ((kt + 1) & 1) * S3_STAGE;
     load_tile(kt + 1, va[0], va2[0], vb[0]);       // past the last tile: out of range -> zeros
     __builtin_amdgcn_sched_barrier(0);
-    s3_compute(acc, cur, wm, wn, l31, half);
+    s3_compute<NPL>(acc, cur, wm, wn, l31, half);
     store_tile(kt + 1, nxt, va[0], va2[0], vb[0]);
     __syncthreads();
   }

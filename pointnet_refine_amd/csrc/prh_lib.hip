@@ -91,14 +91,17 @@ struct Arena {
 // Which GEMM core serves a launch.  PRH_GEMM=fp32 forces the exact fp32 MFMA cores
 // everywhere; default "split" routes large GEMMs to the 3-plane bf16 cores (fp32-level
 // error, 2.67x higher matrix ceiling) and keeps small / odd-shaped ones on the fp32 cores.
-int g_gemm_mode = -1;   // -1: not initialised, 0: fp32 cores only, 1: split-bf16 for large GEMMs
-inline bool split_enabled() {
+// -1: not initialised, 0: fp32 cores only, 1: split-bf16 (3 planes, fp32-accurate) for large
+// GEMMs, 2: plain bf16 operands (1 plane) for large GEMMs - reduced precision, opt-in only
+int g_gemm_mode = -1;
+inline int gemm_mode() {
   if (g_gemm_mode < 0) {
     const char* e = getenv("PRH_GEMM");
-    g_gemm_mode = (e != nullptr && strcmp(e, "fp32") == 0) ? 0 : 1;
+    g_gemm_mode = (e != nullptr && strcmp(e, "fp32") == 0) ? 0 : ((e != nullptr && strcmp(e, "bf16") == 0) ? 2 : 1);
   }
-  return g_gemm_mode != 0;
+  return g_gemm_mode;
 }
+inline bool split_enabled() { return gemm_mode() != 0; }
 inline bool nt_use_s3(int M, int N, int K) {
   return split_enabled() && K >= 64 && K <= 4096 && N >= 128 && M >= 512;   // K cap: coefficient LDS
 }
@@ -144,12 +147,19 @@ int launch_nt(NTParams p, hipStream_t st, StatInfo* si = nullptr) {
       LAUNCH_CHECK();
       p.tiles_n = NTl;
       const long tiles = (long)NTl * cdiv(p.M, S3_BM);
-      static const int attr_rc = allow_big_lds(gemm_nt_s3_kernel<PRO, EPI>);
+      static const int attr_rc = allow_big_lds(gemm_nt_s3_kernel<PRO, EPI, 3>);
+      static const int attr_rc1 = allow_big_lds(gemm_nt_s3_kernel<PRO, EPI, 1>);
       if (attr_rc != PRH_OK) return attr_rc;
-      snprintf(nm, sizeof(nm), "gemm_nt_s3<%d,%d> K=%d N=%d", PRO, EPI, p.K, p.N);
+      if (attr_rc1 != PRH_OK) return attr_rc1;
+      const bool one = gemm_mode() == 2;
+      snprintf(nm, sizeof(nm), "gemm_nt_%s<%d,%d> K=%d N=%d", one ? "b1" : "s3", PRO, EPI, p.K, p.N);
       ProfScope ps(nm, 2.0 * p.M * (double)p.N * p.K, by, st);
-      hipLaunchKernelGGL((gemm_nt_s3_kernel<PRO, EPI>), dim3((unsigned)tiles), dim3(512),
-                         nt_s3_lds(p.K, PRO), st, p, (const char*)p.wprep);
+      if (one)
+        hipLaunchKernelGGL((gemm_nt_s3_kernel<PRO, EPI, 1>), dim3((unsigned)tiles), dim3(512),
+                           nt_s3_lds(p.K, PRO), st, p, (const char*)p.wprep);
+      else
+        hipLaunchKernelGGL((gemm_nt_s3_kernel<PRO, EPI, 3>), dim3((unsigned)tiles), dim3(512),
+                           nt_s3_lds(p.K, PRO), st, p, (const char*)p.wprep);
       LAUNCH_CHECK();
       if (si) { si->count = 2 * cdiv(p.M, S3_BM); si->rows = 128; }
       return PRH_OK;
@@ -221,12 +231,19 @@ int launch_tn(TNParams p, float* slab, float* colsum_slab, float* C, long ldc, f
     bool done = false;
     if constexpr (PROB != PRO_GATE1) {
       if (pl.s3) {
-        static const int attr_rc = allow_big_lds(gemm_tn_s3_kernel<PROA, PROB>);
+        static const int attr_rc = allow_big_lds(gemm_tn_s3_kernel<PROA, PROB, 3>);
+        static const int attr_rc1 = allow_big_lds(gemm_tn_s3_kernel<PROA, PROB, 1>);
         if (attr_rc != PRH_OK) return attr_rc;
-        snprintf(nm, sizeof(nm), "gemm_tn_s3<%d,%d> Mo=%d Ni=%d", PROA, PROB, p.Mo, p.Ni);
+        if (attr_rc1 != PRH_OK) return attr_rc1;
+        const bool one = gemm_mode() == 2;
+        snprintf(nm, sizeof(nm), "gemm_tn_%s<%d,%d> Mo=%d Ni=%d", one ? "b1" : "s3", PROA, PROB, p.Mo, p.Ni);
         ProfScope ps(nm, 2.0 * p.P * (double)p.Mo * p.Ni, by, st);
-        hipLaunchKernelGGL((gemm_tn_s3_kernel<PROA, PROB>), dim3((unsigned)blocks), dim3(512), S3_LDS,
-                           st, p);
+        if (one)
+          hipLaunchKernelGGL((gemm_tn_s3_kernel<PROA, PROB, 1>), dim3((unsigned)blocks), dim3(512),
+                             S3_LDS, st, p);
+        else
+          hipLaunchKernelGGL((gemm_tn_s3_kernel<PROA, PROB, 3>), dim3((unsigned)blocks), dim3(512),
+                             S3_LDS, st, p);
         done = true;
       }
     }
@@ -519,11 +536,11 @@ extern "C" {
 
 const char* prh_last_error(void) { return g_err; }
 int prh_set_gemm_mode(int mode) {
-  if (mode != 0 && mode != 1) return fail(PRH_ERR_ARG, "gemm mode must be 0 (fp32) or 1 (split-bf16)");
+  if (mode < 0 || mode > 2) return fail(PRH_ERR_ARG, "gemm mode must be 0 (fp32), 1 (split-bf16) or 2 (bf16)");
   g_gemm_mode = mode;
   return PRH_OK;
 }
-int prh_get_gemm_mode(void) { return split_enabled() ? 1 : 0; }
+int prh_get_gemm_mode(void) { return gemm_mode(); }
 const char* prh_version(void) { return "pointnet_refine_hip 0.1 (gfx950, fp32 MFMA 32x32x2)"; }
 
 // ------------------------------------------------------------------ Linear

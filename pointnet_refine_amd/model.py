@@ -106,7 +106,9 @@ class PositionalEncoding(nn.Module):
         self.mlp = nn.Sequential(nn.Linear(in_dim, out_dim), nn.ReLU(), nn.Linear(out_dim, out_dim))
 
     def forward(self, xyz):
-        return self.mlp(xyz)
+        # Linear(3,256) stays on torch (3-wide input); Linear(256,256) runs on the HIP cores
+        h = F.relu(F.linear(xyz, self.mlp[0].weight, self.mlp[0].bias))
+        return _lin(h, self.mlp[2].weight, self.mlp[2].bias)
 
 
 class DetrTransformerDecoderLayer(nn.Module):
@@ -243,7 +245,8 @@ class LineRefineNet(nn.Module):
         for i, (decoder_layer, reg_branch) in enumerate(zip(layers, self.reg_branches)):
             pos_tgt = self.pos_emb(current_line_coords)
             tgt = decoder_layer.forward_projected(tgt, k_all[i], v_all[i], query_pos=pos_tgt)
-            delta_offset = reg_branch(tgt)
+            hid = F.relu(_lin(tgt, reg_branch[0].weight, reg_branch[0].bias))       # 256 -> 128 on HIP
+            delta_offset = F.linear(hid, reg_branch[2].weight, reg_branch[2].bias)   # 128 -> 3
             current_line_coords = current_line_coords + delta_offset      # no detach (H5)
             all_pred_offsets.append(current_line_coords - noisy_line)
         return torch.stack(all_pred_offsets)

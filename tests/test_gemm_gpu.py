@@ -94,3 +94,27 @@ def test_split_core_is_fp32_accurate():
     lib.prh_set_gemm_mode(old)
     print("rel-L2 error vs fp64: fp32 core %.3e, split core %.3e" % (errs[0], errs[1]))
     assert errs[0] < 1e-6 and errs[1] < 1e-6
+
+
+def test_bf16_mode_is_reduced_precision_but_sane():
+    """Mode 2 (plain bf16 operands, BASELINE config 3) is opt-in and only bf16-accurate:
+    rel-L2 error vs fp64 in the 1e-3 class, far above the split core's 1e-6."""
+    from pointnet_refine_amd import _lib
+    lib = _lib.lib()
+    m, n, k = 1024, 512, 1024
+    g = torch.Generator(device="cuda").manual_seed(6)
+    a = torch.randn(m, k, device="cuda", generator=g)
+    w = torch.randn(n, k, device="cuda", generator=g)
+    ref = a.double() @ w.double().t()
+    nb = lib.prh_linear_forward_workspace_bytes(m, k, n)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    old = lib.prh_get_gemm_mode()
+    try:
+        lib.prh_set_gemm_mode(2)
+        c = torch.empty(m, n, device="cuda")
+        assert lib.prh_test_gemm_nt(_p(a), _p(w), _p(c), m, n, k, _p(ws), nb, 0, st) == 0
+        err = float((c.double() - ref).norm() / ref.norm())
+    finally:
+        lib.prh_set_gemm_mode(old)
+    assert 1e-4 < err < 1e-2, err

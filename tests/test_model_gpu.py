@@ -155,3 +155,23 @@ def test_batch_4096_points_2048_shapes_run():
         o = O.linerefine_forward(O.as_params(sd), ctx[10:12], noisy[10:12])
     assert out.shape == (6, 64, 32, 3)
     assert maxdiff(out[:, 10:12], o) < 1e-4
+
+
+def test_bf16_mode_loose_gate(golden_dir):
+    """BASELINE config 3 (bf16 arithmetic): eval forward within the LOOSER 5e-2 gate the
+    survey sets for reduced precision (CPU bf16 autocast of the reference shows 1.7e-2)."""
+    from pointnet_refine_amd import _lib
+    lib = _lib.lib()
+    old = lib.prh_get_gemm_mode()
+    lib.prh_set_gemm_mode(2)
+    try:
+        g = np.load(os.path.join(golden_dir, "g1_eval_forward.npz"))
+        m = _model(P.linerefine_state_dict(0)).eval()
+        ctx, noisy, _ = P.synth_batch(8, 256, 4, 32, seed=1234)
+        with torch.no_grad():
+            out = m(ctx.cuda(), noisy.cuda())
+        err = maxdiff(out, g["out"])
+        print("bf16-mode max abs error on out:", err)
+        assert err < 5e-2
+    finally:
+        lib.prh_set_gemm_mode(old)
