@@ -460,7 +460,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TNParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-  int b = blockIdx.x;
+  // XCD-aware id: the tiles of one row split run on one XCD, so the split's rows of A and B
+  // are fetched into that L2 once and shared by its tiles_m x tiles_n blocks
+  int b = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_n = b % p.tiles_n; b /= p.tiles_n;
   const int tile_m = b % p.tiles_m; b /= p.tiles_m;
   const int split = b;
