@@ -97,6 +97,20 @@ inline size_t s3_weight_bytes(int N, int K) {
   return (size_t)((N + S3_BN - 1) / S3_BN) * ((K + S3_BK - 1) / S3_BK) * S3_OPER;
 }
 
+// LDS-DMA of 16 B per lane, hidden from the compiler's wait-count bookkeeping: with the builtin
+// form hipcc drains vmcnt(0) before the next ds_read (it must assume the DMA aliases it), i.e.
+// right behind the issue, exposing the full memory latency every k-tile.  Issued from inline
+// asm the DMA is ours to wait for: a counted s_waitcnt vmcnt(N) before the barrier that
+// publishes the stage (N = younger loads that may stay in flight).  M0 (the LDS base of the
+// wave's 1-KB slice; the hardware adds lane*16) is saved and restored in the same statement.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_addr)
+               : "memory");
+}
+
 // six-product MFMA block: acc += (ah+am+al)*(wh+wm+wl) without the three smallest terms
 __device__ __forceinline__ void mfma6(f32x16& acc, const bf16x8& ah, const bf16x8& am,
                                       const bf16x8& al, const bf16x8& wh, const bf16x8& wm,
@@ -186,19 +200,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
   // loads of tile kt+2.
   float4 ra[2][2], ra2[2][2];
   const char* wsrc = Wp + (size_t)tile_n * KT * S3_OPER + tid * 16;
-  // wave-uniform LDS offset of this wave's 1-KB slice of a W plane (LDS-DMA adds lane*16)
-  const int wdst = S3_OPER + __builtin_amdgcn_readfirstlane(wave) * 1024;
+  // wave-uniform LDS byte address of this wave's 1-KB slice of a W plane in stage 0
+  const unsigned lds0 = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)smem);
+  const unsigned wdst = __builtin_amdgcn_readfirstlane(lds0 + S3_OPER + wave * 1024);
 
   // W planes: pre-split, pre-swizzled image -> straight global->LDS DMA (no registers, no
-  // ds_write); the __syncthreads() that ends the iteration waits for it (vmcnt).
-  auto dma_w = [&](int kt, char* st) {
+  // ds_write), issued from inline asm and waited for by the counted vmcnt that ends the k-tile.
+  auto dma_w = [&](int kt, int stage) {
     const char* q = wsrc + (size_t)(kt < KT ? kt : KT - 1) * S3_OPER;   // tail: harmless re-copy
 #pragma unroll
-    for (int pl = 0; pl < NPL; ++pl)
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(q + pl * S3_PLANE),
-          (__attribute__((address_space(3))) void*)(st + wdst + pl * S3_PLANE), 16, 0, 0);
+    for (int pl = 0; pl < NPL; ++pl) glds16(q + pl * S3_PLANE, wdst + stage * S3_STAGE + pl * S3_PLANE);
   };
+  // A loads issued after the DMA in one k-tile: they may stay in flight across the barrier
+  constexpr int NA = PRO == PRO_GATE1 ? 0 : (PRO == PRO_BNBWD ? 4 : 2);
   // A via buffer loads: descriptor = this block's 256 rows (hardware returns 0 beyond them,
   // so no exec-mask branches and no address clamps), per-lane 32-bit byte offsets computed
   // once; the k advance is added to the per-lane offset (NOT the scalar offset, which the
@@ -268,10 +282,23 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
     constexpr int CS = decltype(cs)::value;
     char* cur = smem + (kt & 1) * S3_STAGE;
     char* nxt = smem + ((kt + 1) & 1) * S3_STAGE;
-    dma_w(kt + 1, nxt);
+    // First "use" of the registers converted in this k-tile, BEFORE any new memory operation is
+    // issued: hipcc waits vmcnt(0) at the first use of a load result while an LDS-DMA is in
+    // flight; here that wait only covers loads issued a whole k-tile ago.  Without it the
+    // wait lands right behind the loads issued below and exposes their full latency.
+    if (PRO != PRO_GATE1) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        asm volatile("" : "+v"(ra[CS][j].x), "+v"(ra[CS][j].y), "+v"(ra[CS][j].z), "+v"(ra[CS][j].w));
+        if (PRO == PRO_BNBWD)
+          asm volatile("" : "+v"(ra2[CS][j].x), "+v"(ra2[CS][j].y), "+v"(ra2[CS][j].z), "+v"(ra2[CS][j].w));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    dma_w(kt + 1, (kt + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);   // DMA strictly before the A loads (vmcnt is in order)
     load_tile(kt + 2, ra[CS ^ 1], ra2[CS ^ 1]);
-    // keep the memory operations at the head of the k-tile (the scheduler otherwise sinks
-    // them next to the barrier, whose vmcnt(0) then exposes their full latency)
+    // keep the memory operations at the head of the k-tile
     __builtin_amdgcn_sched_barrier(0);
     s3_compute<NPL>(acc, cur, wm, wn, l31, half);
     store_tile(kt + 1, nxt, ra[CS], ra2[CS]);
@@ -289,10 +316,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
         __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
       }
     }
+    // the DMA of this k-tile (older than its NA register loads) must have landed
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NA) : "memory");
     __syncthreads();
   };
 
-  dma_w(0, smem);
+  dma_w(0, 0);
+  __builtin_amdgcn_sched_barrier(0);
   load_tile(0, ra[0], ra2[0]);
   load_tile(1, ra[1], ra2[1]);
   if (PRO != PRO_NONE) {
@@ -308,6 +338,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
     __syncthreads();
   }
   store_tile(0, smem, ra[0], ra2[0]);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // first W image landed (prologue only)
   __syncthreads();
   int kt = 0;
   for (; kt + 1 < KT; kt += 2) {
@@ -315,7 +346,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
     iter(kt + 1, std::integral_constant<int, 0>{});
   }
   if (kt < KT) iter(kt, std::integral_constant<int, 1>{});
-  // the stage buffers are free now (the loop ended on a barrier with every DMA drained):
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // the stage buffers are free now (every DMA drained, every wave past its last fragment read):
   // use them as wave-private scratch for the row-major, 16-B-per-lane epilogue
   const bool vec_ok = ((p.N | (int)p.ldc) & 3) == 0 && (p.E1 == nullptr || ((int)p.lde1 & 3) == 0) &&
                       (p.flags & F_E1_ROWVEC) == 0 && (p.C2 == nullptr || ((int)p.ldc2 & 3) == 0);
@@ -457,6 +490,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_s3_kernel(const TNParams p) {
     load_tile(kt + 1, va[0], va2[0], vb[0]);       // past the last tile: out of range -> zeros
     __builtin_amdgcn_sched_barrier(0);
     s3_compute<NPL>(acc, cur, wm, wn, l31, half);
+    // the conversion consumes the loads issued above: keep it BEHIND the MFMAs (the scheduler
+    // otherwise hoists it in front of them and every k-tile pays the full memory latency)
+    __builtin_amdgcn_sched_barrier(0);
     store_tile(kt + 1, nxt, va[0], va2[0], vb[0]);
     __syncthreads();
   }
