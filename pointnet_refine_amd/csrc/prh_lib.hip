@@ -103,9 +103,12 @@ inline int gemm_mode() {
 }
 inline bool split_enabled() { return gemm_mode() != 0; }
 inline bool nt_use_s3(int M, int N, int K) {
-  return split_enabled() && K >= 64 && K <= 4096 && N >= 128 && M >= 512;   // K cap: coefficient LDS
+  // K cap: coefficient LDS image.  Grid floor: a 256x256-tile grid of a few workgroups is
+  // latency-bound (53 us for 4 workgroups measured); small GEMMs go to the 128x128 fp32 core.
+  return split_enabled() && K >= 64 && K <= 4096 && N >= 128 && M >= 512 &&
+         (long)cdiv(M, S3_BM) * cdiv(N, S3_BN) >= 32;
 }
-inline bool tn_use_s3(int P, int Mo, int Ni) { return split_enabled() && Mo >= 128 && Ni >= 64 && P >= 2048; }
+inline bool tn_use_s3(int P, int Mo, int Ni) { return split_enabled() && Mo >= 128 && Ni >= 64 && P >= 8192; }
 
 // Statistics partials: `count` tiles of `rows` rows each
 struct StatInfo { int count = 0; int rows = 64; };
@@ -185,7 +188,7 @@ inline TNPlan tn_plan(int P, int Mo, int Ni, bool allow_s3) {
   pl.tiles_n = cdiv(Ni, tile);
   const int tiles = pl.tiles_m * pl.tiles_n;
   int s = cdiv(pl.s3 ? 768 : 1024, tiles);
-  const int minrows = pl.s3 ? 1024 : 512;
+  const int minrows = pl.s3 ? 512 : 128;
   const int smax = cdiv(P, minrows) < 1 ? 1 : cdiv(P, minrows);
   if (s > smax) s = smax;
   if (s < 1) s = 1;

@@ -101,7 +101,7 @@ def test_bf16_mode_is_reduced_precision_but_sane():
     rel-L2 error vs fp64 in the 1e-3 class, far above the split core's 1e-6."""
     from pointnet_refine_amd import _lib
     lib = _lib.lib()
-    m, n, k = 1024, 512, 1024
+    m, n, k = 4096, 1024, 1024      # large enough to be routed to the 256x256-tile cores
     g = torch.Generator(device="cuda").manual_seed(6)
     a = torch.randn(m, k, device="cuda", generator=g)
     w = torch.randn(n, k, device="cuda", generator=g)
