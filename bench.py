@@ -103,7 +103,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ      # torchrun / torch.distributed.run
+    if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl")     # RCCL on ROCm
     torch.cuda.set_device(local_rank)
@@ -118,7 +119,7 @@ def main():
 
     torch.manual_seed(0)
     model = LineRefineNet().to(dev).train()
-    if world > 1:
+    if launched:
         for p in model.parameters():                 # same start on every rank (DDP does this)
             dist.broadcast(p.data, 0)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
@@ -128,8 +129,8 @@ def main():
     ctx, noisy, target = synthetic_batch(B, N, dev, seed=1234 + rank)
 
     def sync():
-        if world > 1:
-            dist.barrier()
+        if launched:
+            dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize(dev)
 
     for i in range(args.warmup):
@@ -146,7 +147,7 @@ def main():
     dt = time.perf_counter() - t0
     if rank == 0:
         log(f"timed {args.steps} steps in {dt:.3f} s")
-    if world > 1:
+    if launched:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -206,7 +207,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, args.cpu_batch)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if launched:
         dist.destroy_process_group()
 
 

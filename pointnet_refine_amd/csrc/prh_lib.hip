@@ -544,7 +544,7 @@ int prh_set_gemm_mode(int mode) {
   return PRH_OK;
 }
 int prh_get_gemm_mode(void) { return gemm_mode(); }
-const char* prh_version(void) { return "pointnet_refine_hip 0.1 (gfx950, fp32 MFMA 32x32x2)"; }
+const char* prh_version(void) { return "pointnet_refine_hip 0.2 (gfx950: fp32 MFMA 32x32x2 + split-bf16 MFMA 32x32x16 cores)"; }
 
 // ------------------------------------------------------------------ Linear
 size_t prh_linear_forward_workspace_bytes(int rows, int k, int n) {

@@ -49,9 +49,12 @@ class FlatGrads:
         self.rebind()
 
     def all_reduce_mean(self, world_size: int, group=None):
-        if world_size > 1:
+        # runs whenever a process group exists (also at world_size 1 under torchrun, so the
+        # single-GPU launch exercises the same RCCL calls as the 8-GPU one)
+        if dist.is_available() and dist.is_initialized():
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-            self.flat.div_(world_size)
+            if world_size > 1:
+                self.flat.div_(world_size)
 
 
 class FlatBuffers:
@@ -89,7 +92,8 @@ class TrainStep:
         self.chunk = decoder_chunk
         self.world, self.group = world_size, group
         self.grads = FlatGrads(model.parameters())
-        self.bufs = FlatBuffers(model) if (world_size > 1 and broadcast_buffers) else None
+        distributed = dist.is_available() and dist.is_initialized()
+        self.bufs = FlatBuffers(model) if (distributed and broadcast_buffers) else None
 
     def forward_backward(self, context, noisy_line, target):
         m = self.model
