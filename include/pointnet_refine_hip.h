@@ -142,6 +142,22 @@ int prh_mlp_stack_backward(const prh_bn_layer* layers, int n_layers, int relu_la
                            const prh_bn_layer_grad* grads, float* dx, void* workspace,
                            size_t workspace_bytes, int device, void* stream);
 
+/* Fused cross-attention core of DetrTransformerDecoderLayer.cross_attn (src/model.py:84,123-126:
+ * nn.MultiheadAttention(256, 8 heads, dropout on the attention weights), everything between
+ * the in-projections and the out-projection): o = dropout(softmax(q k^T * scale)) v per head
+ * of 32 channels, exact fp32 MFMA, online softmax.
+ *   q [B*M, H*32] (ld ldq), k/v [B*N, H*32] (ld ldk/ldv: may be column blocks of a wider
+ *   projection buffer), o [B*M, H*32], lse [B,H,M] (kept for the backward).
+ * dropout_p = 0 in eval mode; the mask is a counter-based hash of (seed, b, h, query, key). */
+int prh_attn_forward(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
+                     float* o, long ldo, float* lse, int B, int M, int N, int H, float scale,
+                     float dropout_p, unsigned seed, int device, void* stream);
+int prh_attn_backward(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
+                      const float* o, long ldo, const float* lse, const float* dout, long lddo,
+                      float* dq, long lddq, float* dk, long lddk, float* dv, long lddv, int B, int M,
+                      int N, int H, float scale, float dropout_p, unsigned seed, int device,
+                      void* stream);
+
 /* GEMM core selection: environment PRH_GEMM=fp32 forces the exact fp32 MFMA cores
  * (v_mfma_f32_32x32x2_f32) everywhere; the default routes large GEMMs to the split-bf16
  * cores (three bf16 planes per fp32 operand, six v_mfma_f32_32x32x16_bf16 products,

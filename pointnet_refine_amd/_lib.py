@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "libpointnet_refine_hip.so")
 _SOURCES = [os.path.join(_HERE, "csrc", f)
-            for f in ("prh_lib.hip", "prh_gemm.hpp", "prh_gemm_s3.hpp", "prh_kernels.hpp")]
+            for f in ("prh_lib.hip", "prh_gemm.hpp", "prh_gemm_s3.hpp", "prh_attn.hpp", "prh_kernels.hpp")]
 _HEADER = os.path.join(_ROOT, "include", "pointnet_refine_hip.h")
 
 PRH_MAX_LAYERS = 8
@@ -55,6 +55,7 @@ EXPORTS = [
     "prh_mlp_stack_workspace_bytes", "prh_mlp_stack_forward", "prh_mlp_stack_backward",
     "prh_test_gemm_nt", "prh_test_gemm_tn_workspace_bytes", "prh_test_gemm_tn",
     "prh_profile_enable", "prh_profile_count", "prh_profile_reset", "prh_profile_read",
+    "prh_attn_forward", "prh_attn_backward",
     "prh_set_gemm_mode", "prh_get_gemm_mode",
     "prh_last_error", "prh_version",
 ]
@@ -112,6 +113,11 @@ def _bind(lib):
     lib.prh_mlp_stack_backward.restype = i
     lib.prh_mlp_stack_backward.argtypes = [C.POINTER(BnLayer), i, i, vp, i, i, vp, vp, vp, vp, vp,
                                            vp, C.POINTER(BnLayerGrad), vp, vp, sz, i, vp]
+    lib.prh_attn_forward.restype = i
+    lib.prh_attn_forward.argtypes = [vp, lg, vp, lg, vp, lg, vp, lg, vp, i, i, i, i, f, f, C.c_uint, i, vp]
+    lib.prh_attn_backward.restype = i
+    lib.prh_attn_backward.argtypes = [vp, lg, vp, lg, vp, lg, vp, lg, vp, vp, lg, vp, lg, vp, lg, vp, lg,
+                                      i, i, i, i, f, f, C.c_uint, i, vp]
     lib.prh_set_gemm_mode.restype = i
     lib.prh_set_gemm_mode.argtypes = [i]
     lib.prh_get_gemm_mode.restype = i

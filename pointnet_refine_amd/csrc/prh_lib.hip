@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include "prh_gemm.hpp"
+#include "prh_attn.hpp"
 #include "prh_gemm_s3.hpp"
 #include "prh_kernels.hpp"
 
@@ -857,6 +858,63 @@ int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B,
       LAUNCH_CHECK();
     }
   }
+  return PRH_OK;
+}
+
+// ------------------------------------------------------------------ fused cross-attention
+static int check_attn(const AttnParams& a) {
+  if (!a.q || !a.k || !a.v || !a.o || !a.lse || a.B <= 0 || a.M <= 0 || a.N <= 0)
+    return fail(PRH_ERR_ARG, "attention: bad argument");
+  if (a.H <= 0 || a.H % 4) return fail(PRH_ERR_ARG, "attention: heads (%d) must be a multiple of 4", a.H);
+  if ((a.ldq | a.ldk | a.ldv | a.ldo) & 3) return fail(PRH_ERR_ARG, "attention: leading dimensions must be multiples of 4");
+  return PRH_OK;
+}
+
+int prh_attn_forward(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
+                     float* o, long ldo, float* lse, int B, int M, int N, int H, float scale,
+                     float dropout_p, unsigned seed, int device, void* stream) {
+  AttnParams a; memset(&a, 0, sizeof(a));
+  a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.o = o; a.ldo = ldo; a.lse = lse;
+  a.B = B; a.M = M; a.N = N; a.H = H; a.scale = scale; a.seed = seed;
+  if (dropout_p < 0.f || dropout_p >= 1.f) return fail(PRH_ERR_ARG, "attention: dropout_p must be in [0,1)");
+  a.keep_scale = 1.f / (1.f - dropout_p);
+  a.drop_thresh = dropout_p > 0.f ? (unsigned)((double)dropout_p * 4294967296.0) : 0u;
+  TRY(check_attn(a));
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps("attn_fwd", 4.0 * B * H * (double)M * N * 32, 4.0 * (2.0 * B * N * H * 32 + 2.0 * B * M * H * 32), st);
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(B * (H / 4))), dim3(256), 0, st, a);
+  LAUNCH_CHECK();
+  return PRH_OK;
+}
+
+int prh_attn_backward(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
+                      const float* o, long ldo, const float* lse, const float* dout, long lddo,
+                      float* dq, long lddq, float* dk, long lddk, float* dv, long lddv, int B, int M,
+                      int N, int H, float scale, float dropout_p, unsigned seed, int device,
+                      void* stream) {
+  AttnParams a; memset(&a, 0, sizeof(a));
+  a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.o = (float*)o; a.ldo = ldo;
+  a.lse = (float*)lse; a.dout = dout; a.lddo = lddo; a.dq = dq; a.lddq = lddq; a.dk = dk; a.lddk = lddk;
+  a.dv = dv; a.lddv = lddv;
+  a.B = B; a.M = M; a.N = N; a.H = H; a.scale = scale; a.seed = seed;
+  if (dropout_p < 0.f || dropout_p >= 1.f) return fail(PRH_ERR_ARG, "attention: dropout_p must be in [0,1)");
+  a.keep_scale = 1.f / (1.f - dropout_p);
+  a.drop_thresh = dropout_p > 0.f ? (unsigned)((double)dropout_p * 4294967296.0) : 0u;
+  TRY(check_attn(a));
+  if (!dout || !dq || !dk || !dv) return fail(PRH_ERR_ARG, "attention_backward: null gradient pointer");
+  if ((lddo | lddq | lddk | lddv) & 3) return fail(PRH_ERR_ARG, "attention_backward: leading dimensions must be multiples of 4");
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = (size_t)4 * 4 * AT_TILE * sizeof(float);
+  static const int attr_rc = [] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 0 : 1;
+  }();
+  if (attr_rc) return fail(PRH_ERR_HIP, "attention_backward: cannot raise the dynamic LDS limit");
+  ProfScope ps("attn_bwd", 14.0 * B * H * (double)M * N * 32, 4.0 * (4.0 * B * N * H * 32 + 4.0 * B * M * H * 32), st);
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(B * (H / 4))), dim3(256), lds, st, a);
+  LAUNCH_CHECK();
   return PRH_OK;
 }
 

@@ -31,6 +31,21 @@ def _bn_buffers(bn: nn.BatchNorm1d):
     return [bn.running_mean, bn.running_var, bn.num_batches_tracked]
 
 
+def _attn(q, k, v, heads, dropout_p):
+    """softmax(q k^T / sqrt(d)) v with dropout on the weights: the fused HIP kernel when the
+    shapes fit it (heads of 32 channels, GPU fp32), torch SDPA otherwise."""
+    B, M, C = q.shape
+    if q.is_cuda and C == heads * 32 and heads % 4 == 0 and q.dtype == torch.float32:
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if dropout_p > 0.0 else 0
+        return ops.attention(q, k, v, heads, dropout_p, seed)
+    N = k.shape[1]
+    qh = q.reshape(B, M, heads, C // heads).transpose(1, 2)
+    kh = k.reshape(B, N, heads, C // heads).transpose(1, 2)
+    vh = v.reshape(B, N, heads, C // heads).transpose(1, 2)
+    o = F.scaled_dot_product_attention(qh, kh, vh, dropout_p=dropout_p)
+    return o.transpose(1, 2).reshape(B, M, C)
+
+
 def _lin(x, weight, bias):
     """nn.Linear arithmetic on the HIP GEMM cores when the shapes fit them (in/out features
     multiples of 4, GPU fp32); the 3-wide layers (pos_emb input, regression output) stay on
@@ -155,20 +170,13 @@ class DetrTransformerDecoderLayer(nn.Module):
         qk_in = self.with_pos_embed(tgt, query_pos)
         qk = _lin(qk_in, sa.in_proj_weight[:2 * d], sa.in_proj_bias[:2 * d])      # q and k share the input
         vv = _lin(tgt, sa.in_proj_weight[2 * d:], sa.in_proj_bias[2 * d:])
-        qh = qk[..., :d].reshape(B, M, h, d // h).transpose(1, 2)
-        kh = qk[..., d:].reshape(B, M, h, d // h).transpose(1, 2)
-        vh = vv.view(B, M, h, d // h).transpose(1, 2)
-        o = F.scaled_dot_product_attention(qh, kh, vh, dropout_p=sa.dropout if self.training else 0.0)
-        tgt2 = _lin(o.transpose(1, 2).reshape(B, M, d), sa.out_proj.weight, sa.out_proj.bias)
+        o = _attn(qk[..., :d], qk[..., d:], vv, h, sa.dropout if self.training else 0.0)
+        tgt2 = _lin(o, sa.out_proj.weight, sa.out_proj.bias)
         tgt = self.norm1(tgt + self.dropout1(tgt2))
         ca = self.cross_attn
-        N = k_proj.shape[1]
         qp = _lin(self.with_pos_embed(tgt, query_pos), ca.in_proj_weight[:d], ca.in_proj_bias[:d])
-        qh = qp.view(B, M, h, d // h).transpose(1, 2)
-        kh = k_proj.view(B, N, h, d // h).transpose(1, 2)
-        vh = v_proj.view(B, N, h, d // h).transpose(1, 2)
-        o = F.scaled_dot_product_attention(qh, kh, vh, dropout_p=ca.dropout if self.training else 0.0)
-        tgt2 = _lin(o.transpose(1, 2).reshape(B, M, d), ca.out_proj.weight, ca.out_proj.bias)
+        o = _attn(qp, k_proj, v_proj, h, ca.dropout if self.training else 0.0)
+        tgt2 = _lin(o, ca.out_proj.weight, ca.out_proj.bias)
         tgt = self.norm2(tgt + self.dropout2(tgt2))
         hid = self.activation(_lin(tgt, self.linear1.weight, self.linear1.bias))
         tgt2 = _lin(self.dropout(hid), self.linear2.weight, self.linear2.bias)

@@ -319,3 +319,76 @@ class EncoderFn(torch.autograd.Function):
 
 def encoder(x_pm, params, buffers, want_global: bool, training: bool, momentum: float, eps: float):
     return EncoderFn.apply(x_pm, want_global, training, momentum, eps, list(buffers), *params)
+
+
+# ------------------------------------------------------------------------------------------
+# Fused cross-attention core (between in-projections and out-projection)
+# ------------------------------------------------------------------------------------------
+def _rows_view(t: torch.Tensor, name: str):
+    """(B, L, C) tensor whose rows are contiguous and equally spaced (possibly a column block
+    of a wider buffer) -> (data_ptr-carrying tensor, leading dimension)."""
+    if t.dim() != 3 or t.stride(2) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
+        t = t.contiguous()
+    return t, t.stride(1)
+
+
+class AttentionFn(torch.autograd.Function):
+    """o = dropout(softmax(q k^T / sqrt(32))) v per head of 32 channels; q (B,M,C), k/v (B,N,C)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads, dropout_p, seed):
+        _req_gpu_f32(q, "query")
+        _req_gpu_f32(k, "key")
+        _req_gpu_f32(v, "value")
+        B, M, Cq = q.shape
+        N = k.shape[1]
+        if Cq != heads * 32 or k.shape[2] != Cq or v.shape[2] != Cq or heads % 4:
+            raise RuntimeError("pointnet_refine_amd.attention: expects heads of 32 channels, heads % 4 == 0")
+        q = q.contiguous()
+        k, ldk = _rows_view(k, "key")
+        v, ldv = _rows_view(v, "value")
+        o = torch.empty_like(q)
+        lse = torch.empty((B, heads, M), dtype=torch.float32, device=q.device)
+        scale = 1.0 / (32.0 ** 0.5)
+        L.check(L.lib().prh_attn_forward(_p(q), Cq, _p(k), ldk, _p(v), ldv, _p(o), Cq, _p(lse), B, M, N,
+                                         heads, scale, float(dropout_p), int(seed) & 0xFFFFFFFF,
+                                         q.device.index, _stream(q.device)), "prh_attn_forward")
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.cfg = (heads, float(dropout_p), int(seed) & 0xFFFFFFFF, scale, ldk, ldv)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        heads, dropout_p, seed, scale, ldk, ldv = ctx.cfg
+        B, M, Cq = q.shape
+        N = k.shape[1]
+        do = do.contiguous()
+        dq = torch.empty_like(q)
+        dk = torch.empty((B, N, Cq), dtype=torch.float32, device=q.device)
+        dv = torch.empty((B, N, Cq), dtype=torch.float32, device=q.device)
+        L.check(L.lib().prh_attn_backward(_p(q), Cq, _p(k), ldk, _p(v), ldv, _p(o), Cq, _p(lse), _p(do), Cq,
+                                          _p(dq), Cq, _p(dk), Cq, _p(dv), Cq, B, M, N, heads, scale,
+                                          dropout_p, seed, q.device.index, _stream(q.device)),
+                "prh_attn_backward")
+        return dq, dk, dv, None, None, None
+
+
+def attention(q, k, v, heads: int, dropout_p: float = 0.0, seed: int = 0):
+    return AttentionFn.apply(q, k, v, heads, dropout_p, seed)
+
+
+def attention_keep_mask(B, H, M, N, dropout_p, seed, device="cpu"):
+    """The dropout keep-mask the kernels use (counter-based hash of seed, b*H+h, query, key),
+    re-created with integer tensor ops; (B,H,M,N) bool.  For tests and reproducibility."""
+    m32 = 0xFFFFFFFF
+    bh = torch.arange(B * H, dtype=torch.int64, device=device).view(B, H, 1, 1)
+    qq = torch.arange(M, dtype=torch.int64, device=device).view(1, 1, M, 1)
+    kk = torch.arange(N, dtype=torch.int64, device=device).view(1, 1, 1, N)
+    x = (int(seed) & m32) ^ ((bh * 0xC2B2AE3D) & m32) ^ ((qq * 0x9E3779B1) & m32) ^ ((kk * 0x85EBCA77) & m32)
+    x = x ^ (x >> 16)
+    x = (x * 0x85EBCA6B) & m32
+    x = x ^ (x >> 13)
+    x = (x * 0xC2B2AE35) & m32
+    x = x ^ (x >> 16)
+    return x >= int(float(dropout_p) * 4294967296.0)

@@ -1,0 +1,63 @@
+"""Fused cross-attention core (prh_attn_forward/backward through ops.attention) against an
+fp64 written-out reference (the oracle's mha core: softmax(q k^T / sqrt(32)) v per head),
+on strided K/V column blocks like the decoder uses, with ragged N and with dropout (the
+kernel's counter-based keep-mask is re-created by ops.attention_keep_mask)."""
+import pytest
+import torch
+
+from conftest import maxdiff, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(q, k, v, H, keep=None, p=0.0):
+    B, M, C = q.shape
+    N = k.shape[1]
+    d = C // H
+    qh = q.double().view(B, M, H, d).transpose(1, 2)
+    kh = k.double().view(B, N, H, d).transpose(1, 2)
+    vh = v.double().view(B, N, H, d).transpose(1, 2)
+    att = torch.softmax(qh @ kh.transpose(-1, -2) / d ** 0.5, dim=-1)
+    if keep is not None:
+        att = att * keep.to(att.dtype) / (1.0 - p)
+    return (att @ vh).transpose(1, 2).reshape(B, M, C)
+
+
+@pytest.mark.parametrize("B,M,N,p", [(3, 32, 64, 0.0), (2, 32, 1000, 0.0), (5, 32, 33, 0.0),
+                                     (2, 32, 257, 0.1), (1, 64, 96, 0.25)])
+def test_attention_fwd_bwd(B, M, N, p):
+    from pointnet_refine_amd import ops
+    H, C = 8, 256
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    q = torch.randn(B, M, C, generator=g)
+    kv = torch.randn(B, N, 6 * C, generator=g)          # K/V as column blocks of a wide buffer
+    up = torch.randn(B, M, C, generator=g)
+    seed = 1234567
+    keep = ops.attention_keep_mask(B, H, M, N, p, seed) if p > 0 else None
+
+    qr, kvr = q.clone().requires_grad_(True), kv.clone().requires_grad_(True)
+    o_ref = _ref(qr, kvr[..., 2 * C:3 * C], kvr[..., 4 * C:5 * C], H, keep, p)
+    (o_ref * up.double()).sum().backward()
+
+    qg, kvg = q.cuda().requires_grad_(True), kv.cuda().requires_grad_(True)
+    o = ops.attention(qg, kvg[..., 2 * C:3 * C], kvg[..., 4 * C:5 * C], H, p, seed)
+    (o * up.cuda()).sum().backward()
+    assert maxdiff(o, o_ref) < 2e-5
+    assert rel_l2(qr.grad, qg.grad) < 2e-5
+    assert rel_l2(kvr.grad, kvg.grad) < 2e-5
+    # untouched column blocks receive exactly zero
+    assert float(kvg.grad[..., :2 * C].abs().max()) == 0.0
+
+
+def test_attention_dropout_rate_and_determinism():
+    from pointnet_refine_amd import ops
+    keep = ops.attention_keep_mask(4, 8, 32, 512, 0.1, 99)
+    rate = 1.0 - keep.float().mean().item()
+    assert abs(rate - 0.1) < 5e-3
+    q = torch.randn(2, 32, 256, device="cuda")
+    k = torch.randn(2, 300, 256, device="cuda")
+    v = torch.randn(2, 300, 256, device="cuda")
+    a = ops.attention(q, k, v, 8, 0.1, 7)
+    b = ops.attention(q, k, v, 8, 0.1, 7)
+    c = ops.attention(q, k, v, 8, 0.1, 8)
+    assert torch.equal(a, b) and not torch.equal(a, c)
