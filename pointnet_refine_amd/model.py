@@ -159,7 +159,7 @@ class DetrTransformerDecoderLayer(nn.Module):
         tgt = self.norm3(tgt + self.dropout3(tgt2))
         return tgt
 
-    def forward_projected(self, tgt, k_proj, v_proj, query_pos=None):
+    def forward_projected(self, tgt, k_proj, v_proj, query_pos=None, kv_block=None):
         """Same layer with the cross-attention key/value projections already applied
         (k_proj = (memory+pos) Wk^T + bk, v_proj = memory Wv^T + bv, each (B,N,C), possibly a
         strided column block).  nn.MultiheadAttention's semantics written out: 8 heads of 32
@@ -175,7 +175,13 @@ class DetrTransformerDecoderLayer(nn.Module):
         tgt = self.norm1(tgt + self.dropout1(tgt2))
         ca = self.cross_attn
         qp = _lin(self.with_pos_embed(tgt, query_pos), ca.in_proj_weight[:d], ca.in_proj_bias[:d])
-        o = _attn(qp, k_proj, v_proj, h, ca.dropout if self.training else 0.0)
+        pdrop = ca.dropout if self.training else 0.0
+        if kv_block is not None:      # k_proj / v_proj are the wide buffers, kv_block picks the block
+            token, arena, blk = kv_block
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if pdrop > 0.0 else 0
+            o = ops.attention_block(qp, k_proj, v_proj, token, arena, blk, h, pdrop, seed)
+        else:
+            o = _attn(qp, k_proj, v_proj, h, pdrop)
         tgt2 = _lin(o, ca.out_proj.weight, ca.out_proj.bias)
         tgt = self.norm2(tgt + self.dropout2(tgt2))
         hid = self.activation(_lin(tgt, self.linear1.weight, self.linear1.bias))
@@ -244,15 +250,25 @@ class LineRefineNet(nn.Module):
         bk = torch.cat([l.cross_attn.in_proj_bias[d:2 * d] for l in layers])
         wv = torch.cat([l.cross_attn.in_proj_weight[2 * d:] for l in layers])
         bv = torch.cat([l.cross_attn.in_proj_bias[2 * d:] for l in layers])
-        # split (not slicing): its backward is one concatenation instead of six zero-filled
-        # full-size gradient buffers that autograd then adds up
-        k_all = ops.linear(mempos, wk, bk).split(d, dim=-1)         # 6 x (B, N, 256) views
-        v_all = ops.linear(memory, wv, bv).split(d, dim=-1)
+        k_all = ops.linear(mempos, wk, bk)                          # (B, N, 6*256)
+        v_all = ops.linear(memory, wv, bv)
+        fused = k_all.is_cuda and d == 256
+        if fused:
+            # the fused attention kernels read column block i of k_all / v_all in place and
+            # write dK / dV straight into one gradient buffer each (ops.GradArena): no
+            # per-layer K/V tensors, no concatenation of their gradients
+            token, arena = ops.kv_token(k_all, v_all, d)
+        else:
+            k_split, v_split = k_all.split(d, dim=-1), v_all.split(d, dim=-1)
         current_line_coords = noisy_line.clone()
         all_pred_offsets = []
         for i, (decoder_layer, reg_branch) in enumerate(zip(layers, self.reg_branches)):
             pos_tgt = self.pos_emb(current_line_coords)
-            tgt = decoder_layer.forward_projected(tgt, k_all[i], v_all[i], query_pos=pos_tgt)
+            if fused:
+                tgt = decoder_layer.forward_projected(tgt, k_all, v_all, query_pos=pos_tgt,
+                                                      kv_block=(token, arena, i))
+            else:
+                tgt = decoder_layer.forward_projected(tgt, k_split[i], v_split[i], query_pos=pos_tgt)
             hid = F.relu(_lin(tgt, reg_branch[0].weight, reg_branch[0].bias))       # 256 -> 128 on HIP
             delta_offset = F.linear(hid, reg_branch[2].weight, reg_branch[2].bias)   # 128 -> 3
             current_line_coords = current_line_coords + delta_offset      # no detach (H5)

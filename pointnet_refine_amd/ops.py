@@ -332,50 +332,132 @@ def _rows_view(t: torch.Tensor, name: str):
     return t, t.stride(1)
 
 
-class AttentionFn(torch.autograd.Function):
-    """o = dropout(softmax(q k^T / sqrt(32))) v per head of 32 channels; q (B,M,C), k/v (B,N,C)."""
+class GradArena:
+    """Gradient buffers of the batched K/V projections, filled block by block by the
+    attention backward of each decoder layer (no per-layer dK/dV tensors, no concatenation)."""
+
+    def __init__(self):
+        self.dk = None
+        self.dv = None
+        self.written = set()
+
+
+class KVTokenFn(torch.autograd.Function):
+    """Ties the arena to autograd: returns a scalar token every attention call takes as an
+    input; its backward runs after ALL those calls' backwards and hands the arena buffers on
+    as the gradients of k_all / v_all."""
 
     @staticmethod
-    def forward(ctx, q, k, v, heads, dropout_p, seed):
+    def forward(ctx, k_all, v_all, arena, block):
+        ctx.arena, ctx.block = arena, block
+        ctx.shape, ctx.dev = tuple(k_all.shape), k_all.device
+        return k_all.new_zeros(())
+
+    @staticmethod
+    def backward(ctx, dtoken):
+        a = ctx.arena
+        nblk = ctx.shape[-1] // ctx.block
+        if a.dk is None:
+            a.dk = torch.zeros(ctx.shape, dtype=torch.float32, device=ctx.dev)
+            a.dv = torch.zeros(ctx.shape, dtype=torch.float32, device=ctx.dev)
+        else:
+            for i in range(nblk):
+                if i not in a.written:
+                    a.dk[..., i * ctx.block:(i + 1) * ctx.block].zero_()
+                    a.dv[..., i * ctx.block:(i + 1) * ctx.block].zero_()
+        dk, dv = a.dk, a.dv
+        a.dk = a.dv = None
+        a.written = set()
+        return dk, dv, None, None
+
+
+class AttentionFn(torch.autograd.Function):
+    """o = dropout(softmax(q k^T / sqrt(32))) v per head of 32 channels; q (B,M,C), k/v (B,N,C).
+    With (token, arena, block) the key/value operands are column block `block` of wide
+    projection buffers and their gradients go straight into the arena."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads, dropout_p, seed, token=None, arena=None, block=0):
         _req_gpu_f32(q, "query")
         _req_gpu_f32(k, "key")
         _req_gpu_f32(v, "value")
         B, M, Cq = q.shape
         N = k.shape[1]
-        if Cq != heads * 32 or k.shape[2] != Cq or v.shape[2] != Cq or heads % 4:
+        if Cq != heads * 32 or heads % 4:
             raise RuntimeError("pointnet_refine_amd.attention: expects heads of 32 channels, heads % 4 == 0")
         q = q.contiguous()
-        k, ldk = _rows_view(k, "key")
-        v, ldv = _rows_view(v, "value")
+        if arena is not None:
+            if not (k.is_contiguous() and v.is_contiguous() and k.shape == v.shape and k.shape[2] % Cq == 0):
+                raise RuntimeError("pointnet_refine_amd.attention: arena mode needs contiguous (B,N,n*C) K/V")
+            ldk = ldv = k.shape[2]
+            koff = voff = block * Cq
+        else:
+            if k.shape[2] != Cq or v.shape[2] != Cq:
+                raise RuntimeError("pointnet_refine_amd.attention: key/value width must equal the query width")
+            k, ldk = _rows_view(k, "key")
+            v, ldv = _rows_view(v, "value")
+            koff = voff = 0
         o = torch.empty_like(q)
         lse = torch.empty((B, heads, M), dtype=torch.float32, device=q.device)
         scale = 1.0 / (32.0 ** 0.5)
-        L.check(L.lib().prh_attn_forward(_p(q), Cq, _p(k), ldk, _p(v), ldv, _p(o), Cq, _p(lse), B, M, N,
+        kp = C.c_void_p(k.data_ptr() + 4 * koff)
+        vp = C.c_void_p(v.data_ptr() + 4 * voff)
+        L.check(L.lib().prh_attn_forward(_p(q), Cq, kp, ldk, vp, ldv, _p(o), Cq, _p(lse), B, M, N,
                                          heads, scale, float(dropout_p), int(seed) & 0xFFFFFFFF,
                                          q.device.index, _stream(q.device)), "prh_attn_forward")
         ctx.save_for_backward(q, k, v, o, lse)
-        ctx.cfg = (heads, float(dropout_p), int(seed) & 0xFFFFFFFF, scale, ldk, ldv)
+        ctx.cfg = (heads, float(dropout_p), int(seed) & 0xFFFFFFFF, scale, ldk, ldv, koff, voff)
+        ctx.arena, ctx.block = arena, block
         return o
 
     @staticmethod
     def backward(ctx, do):
         q, k, v, o, lse = ctx.saved_tensors
-        heads, dropout_p, seed, scale, ldk, ldv = ctx.cfg
+        heads, dropout_p, seed, scale, ldk, ldv, koff, voff = ctx.cfg
         B, M, Cq = q.shape
         N = k.shape[1]
         do = do.contiguous()
         dq = torch.empty_like(q)
-        dk = torch.empty((B, N, Cq), dtype=torch.float32, device=q.device)
-        dv = torch.empty((B, N, Cq), dtype=torch.float32, device=q.device)
-        L.check(L.lib().prh_attn_backward(_p(q), Cq, _p(k), ldk, _p(v), ldv, _p(o), Cq, _p(lse), _p(do), Cq,
-                                          _p(dq), Cq, _p(dk), Cq, _p(dv), Cq, B, M, N, heads, scale,
+        a = ctx.arena
+        if a is not None:
+            if a.dk is None:
+                a.dk = torch.empty_like(k)
+                a.dv = torch.empty_like(v)
+            dk, dv, lddk = a.dk, a.dv, k.shape[2]
+            dkp = C.c_void_p(dk.data_ptr() + 4 * koff)
+            dvp = C.c_void_p(dv.data_ptr() + 4 * voff)
+            a.written.add(ctx.block)
+        else:
+            dk = torch.empty((B, N, Cq), dtype=torch.float32, device=q.device)
+            dv = torch.empty((B, N, Cq), dtype=torch.float32, device=q.device)
+            lddk, dkp, dvp = Cq, _p(dk), _p(dv)
+        kp = C.c_void_p(k.data_ptr() + 4 * koff)
+        vp = C.c_void_p(v.data_ptr() + 4 * voff)
+        L.check(L.lib().prh_attn_backward(_p(q), Cq, kp, ldk, vp, ldv, _p(o), Cq, _p(lse), _p(do), Cq,
+                                          _p(dq), Cq, dkp, lddk, dvp, lddk, B, M, N, heads, scale,
                                           dropout_p, seed, q.device.index, _stream(q.device)),
                 "prh_attn_backward")
-        return dq, dk, dv, None, None, None
+        if a is not None:
+            return dq, None, None, None, None, None, torch.zeros((), device=q.device), None, None
+        return dq, dk, dv, None, None, None, None, None, None
 
 
 def attention(q, k, v, heads: int, dropout_p: float = 0.0, seed: int = 0):
     return AttentionFn.apply(q, k, v, heads, dropout_p, seed)
+
+
+def kv_token(k_all, v_all, block: int):
+    """(token, arena) for attention_block(): call once per batched K/V projection pair."""
+    arena = GradArena()
+    return KVTokenFn.apply(k_all, v_all, arena, block), arena
+
+
+def attention_block(q, k_all, v_all, token, arena, block_index: int, heads: int,
+                    dropout_p: float = 0.0, seed: int = 0):
+    """Attention against column block `block_index` of the wide projections k_all / v_all
+    ((B,N,n*C), contiguous); their gradients are assembled in the arena (see kv_token)."""
+    return AttentionFn.apply(q, k_all.detach(), v_all.detach(), heads, dropout_p, seed, token, arena,
+                             block_index)
 
 
 def attention_keep_mask(B, H, M, N, dropout_p, seed, device="cpu"):

@@ -61,3 +61,33 @@ def test_attention_dropout_rate_and_determinism():
     b = ops.attention(q, k, v, 8, 0.1, 7)
     c = ops.attention(q, k, v, 8, 0.1, 8)
     assert torch.equal(a, b) and not torch.equal(a, c)
+
+
+def test_attention_arena_blocks_match_plain_path():
+    """Six attention calls against column blocks of one wide K/V buffer with the gradient
+    arena give the same outputs and the same dK_all/dV_all as six plain calls on slices."""
+    from pointnet_refine_amd import ops
+    B, M, N, H, C = 2, 32, 200, 8, 256
+    g = torch.Generator().manual_seed(11)
+    q = [torch.randn(B, M, C, generator=g).cuda().requires_grad_(True) for _ in range(6)]
+    k_all = torch.randn(B, N, 6 * C, generator=g).cuda()
+    v_all = torch.randn(B, N, 6 * C, generator=g).cuda()
+    up = torch.randn(B, M, C, generator=g).cuda()
+
+    ka, va = k_all.clone().requires_grad_(True), v_all.clone().requires_grad_(True)
+    token, arena = ops.kv_token(ka, va, C)
+    outs = [ops.attention_block(q[i], ka, va, token, arena, i, H) for i in (0, 1, 2, 4, 5)]   # block 3 unused
+    sum((o * up).sum() for o in outs).backward()
+    dq_a = [t.grad.clone() if t.grad is not None else None for t in q]
+    for t in q:
+        t.grad = None
+
+    kb, vb = k_all.clone().requires_grad_(True), v_all.clone().requires_grad_(True)
+    outs_b = [ops.attention(q[i], kb[..., i * C:(i + 1) * C], vb[..., i * C:(i + 1) * C], H) for i in (0, 1, 2, 4, 5)]
+    sum((o * up).sum() for o in outs_b).backward()
+    for a, b in zip(outs, outs_b):
+        assert torch.equal(a, b)
+    assert maxdiff(ka.grad, kb.grad) < 1e-6 and maxdiff(va.grad, vb.grad) < 1e-6
+    assert float(ka.grad[..., 3 * C:4 * C].abs().max()) == 0.0       # unused block is zero-filled
+    for i in (0, 1, 2, 4, 5):
+        assert maxdiff(dq_a[i], q[i].grad) < 1e-6
