@@ -35,6 +35,27 @@ SPLIT_PRODUCTS = 6                 # bf16 MFMA products per fp32-accurate MAC on
 HBM_PEAK_GBS = 8000.0
 
 
+def pmc_traffic(dname, batch, points, mode):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/r01_pmc_traffic_B4096.json: FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc
+    runs of this same command, scripts/pmc_traffic.sh).  Counters cannot be read from inside
+    the benchmark, so this is a lookup valid for the configuration it was taken on; null
+    otherwise."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_B4096.json")
+    if not (os.path.exists(path) and batch == 4096 and points == 1024 and mode == 1):
+        return None
+    import re
+    m = re.match(r"gemm_(nt|tn)_s3<(\d),(\d)>", dname)
+    if not m:
+        return None
+    tmpl = f"prh::gemm_{m.group(1)}_s3_kernel<{m.group(2)}, {m.group(3)}, 3>"
+    cands = [r for r in json.load(open(path)) if r["kernel"] == tmpl]
+    if not cands:
+        return None
+    r = max(cands, key=lambda r: r["fetch_bytes_per_launch"])      # the fusion-layer launch
+    return r["fetch_bytes_per_launch"] + (r["write_bytes_per_launch"] or 0.0)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -180,7 +201,10 @@ def main():
                                               "157.3 TF fp32 MFMA (v_mfma_f32_32x32x2_f32)")),
                 "issued_mfma_tflops": round(achieved * (SPLIT_PRODUCTS if split else 1), 1),
                 "vs_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": cnt,
+                "traffic": pmc_traffic(dname, B, N, lib.prh_get_gemm_mode()),
+                "traffic_source": "profiles/r01_pmc_traffic_B4096.json (rocprofv3 --pmc FETCH_SIZE x2, WRITE_SIZE)",
+                "algorithmic_bytes": bytes_,
+                "avg_launch_ms": round(avg_ms, 4), "launches": cnt,
                 "algorithmic_gbs": round(bytes_ / (avg_ms * 1e-3) / 1e9, 1),
                 "hbm_frac": round(bytes_ / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "hip_gemm_ms_per_step": round(hip_ms / args.steps, 2)}
