@@ -102,10 +102,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;           // per query = per lane column
 
+    float kn[16], vn[16];                           // next tile, loaded one tile ahead
+    load_rows16(p.k, p.ldk, (long)b * p.N, p.N, col0, lane, kn);
+    load_rows16(p.v, p.ldv, (long)b * p.N, p.N, col0, lane, vn);
     for (int k0 = 0; k0 < p.N; k0 += 32) {
       float ka[16], va[16];
-      load_rows16(p.k, p.ldk, (long)b * p.N + k0, p.N - k0, col0, lane, ka);
-      load_rows16(p.v, p.ldv, (long)b * p.N + k0, p.N - k0, col0, lane, va);
+#pragma unroll
+      for (int t = 0; t < 16; ++t) { ka[t] = kn[t]; va[t] = vn[t]; }
+      if (k0 + 32 < p.N) {
+        load_rows16(p.k, p.ldk, (long)b * p.N + k0 + 32, p.N - k0 - 32, col0, lane, kn);
+        load_rows16(p.v, p.ldv, (long)b * p.N + k0 + 32, p.N - k0 - 32, col0, lane, vn);
+      }
       tile_store(vt, lane, va);
       // S^T[key][q]: rows = keys in registers, column = query on the lane
       f32x16 s;
@@ -202,10 +209,17 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) dqacc[r] = 0.f;
 
+    float kn[16], vn[16];                           // next tile, loaded one tile ahead
+    load_rows16(p.k, p.ldk, (long)b * p.N, p.N, col0, lane, kn);
+    load_rows16(p.v, p.ldv, (long)b * p.N, p.N, col0, lane, vn);
     for (int k0 = 0; k0 < p.N; k0 += 32) {
       float ka[16], va[16];
-      load_rows16(p.k, p.ldk, (long)b * p.N + k0, p.N - k0, col0, lane, ka);
-      load_rows16(p.v, p.ldv, (long)b * p.N + k0, p.N - k0, col0, lane, va);
+#pragma unroll
+      for (int t = 0; t < 16; ++t) { ka[t] = kn[t]; va[t] = vn[t]; }
+      if (k0 + 32 < p.N) {
+        load_rows16(p.k, p.ldk, (long)b * p.N + k0 + 32, p.N - k0 - 32, col0, lane, kn);
+        load_rows16(p.v, p.ldv, (long)b * p.N + k0 + 32, p.N - k0 - 32, col0, lane, vn);
+      }
       tile_store(ktile, lane, ka);
       const bool key_ok = (k0 + l31) < p.N;          // this lane's key (keys-on-lanes form)
 

@@ -126,7 +126,7 @@ __device__ __forceinline__ void mfma6(f32x16& acc, const bf16x8& ah, const bf16x
 // one k-tile of MFMAs for a wave tile of 128 x 64 out of the stage at `st`.
 // NPL = 3: fp32-accurate six-product form; NPL = 1: plain bf16 operands (h plane only),
 // one product - the reduced-precision mode of BASELINE config 3.
-template <int NPL>
+template <int NPL, int I0 = 0, int I1 = 4>
 __device__ __forceinline__ void s3_compute(f32x16 (&acc)[4][2], const char* st, int wm, int wn,
                                            int l31, int half) {
   bf16x8 w[2][NPL];
@@ -138,7 +138,7 @@ __device__ __forceinline__ void s3_compute(f32x16 (&acc)[4][2], const char* st, 
     for (int pl = 0; pl < NPL; ++pl) w[j][pl] = *reinterpret_cast<const bf16x8*>(q + pl * S3_PLANE);
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = I0; i < I1; ++i) {
     const int row = wm + i * 32 + l31;
     const char* q = st + s3_off(row, half * 8);
     bf16x8 a[NPL];
@@ -489,11 +489,20 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_s3_kernel(const TNParams p) {
     char* nxt = smem + ((kt + 1) & 1) * S3_STAGE;
     load_tile(kt + 1, va[0], va2[0], vb[0]);       // past the last tile: out of range -> zeros
     __builtin_amdgcn_sched_barrier(0);
-    s3_compute<NPL>(acc, cur, wm, wn, l31, half);
-    // the conversion consumes the loads issued above: keep it BEHIND the MFMAs (the scheduler
-    // otherwise hoists it in front of them and every k-tile pays the full memory latency)
+    // first half of the MFMAs covers the latency of the loads issued above ...
+    s3_compute<NPL, 0, 2>(acc, cur, wm, wn, l31, half);
     __builtin_amdgcn_sched_barrier(0);
+    // ... the second half is interleaved with the conversion of the tile they brought in
+    // (1 MFMA : 8 VALU - the wgrad core splits both operands, ~200 VALU per k-tile)
+    s3_compute<NPL, 2, 4>(acc, cur, wm, wn, l31, half);
     store_tile(kt + 1, nxt, va[0], va2[0], vb[0]);
+    if constexpr (NPL == 3) {
+#pragma unroll
+      for (int g = 0; g < 24; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+      }
+    }
     __syncthreads();
   }
 
