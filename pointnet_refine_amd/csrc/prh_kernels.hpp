@@ -93,7 +93,7 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
 // grid = ceil(N/32), block 1024.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(
-    const float* __restrict__ ws_a, const float* __restrict__ ws_b, int R2, int P, int N,
+    const float* __restrict__ ws_a, const float* __restrict__ ws_b, int R2, long ws_ld, int P, int N,
     const float* __restrict__ gamma, const float* __restrict__ mean,
     const float* __restrict__ rstd, int training, float* ca, float* cb, float* cc,
     float* dgamma, float* dbeta, float* dbias) {
@@ -104,8 +104,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(
   double s1 = 0.0, s2 = 0.0;
   if (ok)
     for (int i = g; i < R2; i += 32) {
-      s1 += (double)ws_a[(size_t)i * N + col];
-      s2 += (double)ws_b[(size_t)i * N + col];
+      s1 += (double)ws_a[(size_t)i * ws_ld + col];      // ws may be a column block of a wider
+      s2 += (double)ws_b[(size_t)i * ws_ld + col];      // partial array (row stride ws_ld)
     }
   red[0][g][c] = s1;
   red[1][g][c] = s2;

@@ -112,7 +112,7 @@ inline bool nt_use_s3(int M, int N, int K) {
 inline bool tn_use_s3(int P, int Mo, int Ni) { return split_enabled() && Mo >= 128 && Ni >= 64 && P >= 8192; }
 
 // Statistics partials: `count` tiles of `rows` rows each
-struct StatInfo { int count = 0; int rows = 64; };
+struct StatInfo { int count = 0; int rows = 64; long ld = 0; long off = 0; };   // ld 0: = layer width
 inline int stat_tiles_max(int P) { return 2 * cdiv(P, BM); }   // largest count any producer writes
 
 template <typename K>
@@ -421,8 +421,9 @@ int stack_backward(const prh_bn_layer* ly, int L, const float* x, int P, int tra
   for (int l = L - 1; l >= 0; --l) {
     const int co = ly[l].cout, o = d.off[l];
     // 1. statistics -> BN-backward coefficients, dgamma, dbeta, dbias
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(co, 32)), dim3(1024), 0, st, w.ws_a,
-                       w.ws_b, si.count, P, co, ly[l].gamma, mean + o, rstd + o, training,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(co, 32)), dim3(1024), 0, st,
+                       w.ws_a + si.off, w.ws_b + si.off, si.count, si.ld ? si.ld : (long)co, P, co,
+                       ly[l].gamma, mean + o, rstd + o, training,
                        sc.ca, sc.cb, sc.cc, gr ? gr[l].dgamma : nullptr, gr ? gr[l].dbeta : nullptr,
                        gr ? gr[l].db : nullptr);
     LAUNCH_CHECK();
@@ -458,6 +459,7 @@ int stack_backward(const prh_bn_layer* ly, int L, const float* x, int P, int tra
       p.ws_a = w.ws_a; p.ws_b = w.ws_b; p.wprep = w.wprep;
       p.flags = F_ACCUM | F_MASK | F_STATS;
       TRY((launch_nt<PRO_BNBWD, EPI_DGRAD>(p, st, &si)));
+      si.ld = 0; si.off = 0;
     } else if (dx != nullptr) {
       // dx = dz_0 W_0  (W_0^T is [cin0p, cout] with zero pad rows)
       const float* w0 = ly[0].w; int kk = d.cin0;
@@ -793,7 +795,7 @@ int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B,
                      sv->bn_shift + cat, P, N, od, d_fused, w.ws_a, w.ws_b);
   LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(od, 32)), dim3(1024), 0, st, w.ws_a, w.ws_b,
-                     cdiv(P, 64), P, od, prm->fusion.gamma, sv->bn_mean + cat, sv->bn_rstd + cat,
+                     cdiv(P, 64), (long)od, P, od, prm->fusion.gamma, sv->bn_mean + cat, sv->bn_rstd + cat,
                      training, sc.ca, sc.cb, sc.cc, gr->fusion.dgamma, gr->fusion.dbeta,
                      gr->fusion.db);
   LAUNCH_CHECK();
@@ -801,6 +803,7 @@ int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B,
 
   // (2) fusion conv: wgrad over the virtual concat, dgrad into dy_cat (masked per layer),
   //     with layer-5 BN-backward partials (the only block that is complete here)
+  StatInfo si5;
   if (gr->fusion.dw) {
     TNParams t; memset(&t, 0, sizeof(t));
     t.A = d_fused; t.lda = od; t.A2 = sv->z_fus; t.lda2 = od; t.pa = sc.ca; t.pb = sc.cb; t.pc = sc.cc;
@@ -815,20 +818,16 @@ int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B,
     p.W = sc.wT; p.ldw = od; p.M = P; p.N = cat; p.K = od;
     p.C = dy_cat; p.ldc = cat; p.E1 = sv->z_cat; p.lde1 = cat; p.es = sv->bn_scale; p.et = sv->bn_shift;
     p.wprep = w.wprep;
-    p.flags = F_MASK;
-    TRY((launch_nt<PRO_BNBWD, EPI_DGRAD>(p, st)));
-  }
-  // layer-5 partials: its block of dy_cat is final (no later conv feeds on it)
-  {
-    const int o5 = d.off[4], c5 = prm->conv[4].cout;
-    hipLaunchKernelGGL(bn_dy_stats_kernel, dim3(cdiv(P, 64), cdiv(c5, 64)), dim3(256), 0, st,
-                       dy_cat + o5, (long)cat, sv->z_cat + o5, (long)cat, sv->bn_scale + o5,
-                       sv->bn_shift + o5, P, c5, 0, dy_cat + o5, (long)cat, w.ws_a, w.ws_b);
-    LAUNCH_CHECK();
+    // BN-backward partial sums of every column ride on the epilogue; only layer 5's block of
+    // them is final here (no later conv adds into it) and is consumed below - the blocks of
+    // layers 1..4 are recomputed by the dgrad that completes them
+    p.ws_a = w.ws_a; p.ws_b = w.ws_b;
+    p.flags = F_MASK | F_STATS;
+    TRY((launch_nt<PRO_BNBWD, EPI_DGRAD>(p, st, &si5)));
+    si5.ld = cat; si5.off = d.off[4];
   }
   // (3) conv5..conv1
   float* dx = d_ctx;
-  StatInfo si5; si5.count = cdiv(P, 64); si5.rows = 64;
   TRY(stack_backward(prm->conv, 5, ctx, P, training, dy_cat, (long)cat, sv->z_cat, (long)cat,
                      sv->bn_scale, sv->bn_shift, sv->bn_mean, sv->bn_rstd, gr->conv, dx, w, sc, si5,
                      st));
