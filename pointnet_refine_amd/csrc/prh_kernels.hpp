@@ -9,65 +9,100 @@
 namespace prh {
 
 // ---------------------------------------------------------------------------------------
-// BatchNorm forward statistics.  Input: per-wave-tile (64 or 128 rows) partials written by
-// gemm_nt<.., EPI_BIAS_STATS>: ws_sum[i][c] = sum of the tile's `tile_rows` rows, ws_m2[i][c] = sum of
-// squared deviations from the TILE mean (Chan et al. pairwise form, so no E[x^2]-E[x]^2
-// cancellation).  Output: mean, rstd, scale = gamma*rstd, shift = beta - mean*scale, and
-// the running-stat update of nn.BatchNorm1d (momentum, UNBIASED variance).
-// grid = ceil(N/32), block = 1024 = 32 columns x 32 row groups.
+// BatchNorm statistics, two stages.  The GEMM epilogues leave per-wave-tile partials
+// ws_a/ws_b [R][ld] (R = tens of thousands at B=4096).  Stage 1 compresses them into
+// BN_SLICES slices of doubles with enough workgroups to use the chip
+// (grid = ceil(N/32) x BN_SLICES, block 256 = 32 columns x 8 row lanes); stage 2 (one thread per
+// column) combines the slices and writes the results.
+//   forward : ws_a = tile sum, ws_b = tile M2 about the TILE mean (Chan et al. pairwise form,
+//             so no E[x^2]-E[x]^2 cancellation); slice record = (n, sum, M2 about slice mean)
+//   backward: ws_a = sum dy, ws_b = sum dy*z; slice record = (sum_a, sum_b, -)
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void bn_fwd_finalize_kernel(
-    const float* __restrict__ ws_sum, const float* __restrict__ ws_m2, int R2, int tile_rows, int P,
-    int N, const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
-    float* running_var, int64_t* nbt, float momentum, float eps, float* mean_out,
-    float* rstd_out, float* scale_out, float* shift_out) {
-  __shared__ double red[32][33];
-  __shared__ double mu_s[32];
+constexpr int BN_SLICES = 32;
+
+__global__ __launch_bounds__(256) void bn_stage1_kernel(const float* __restrict__ ws_a,
+                                                        const float* __restrict__ ws_b, int R,
+                                                        long ld, int N, int tile_rows, int P,
+                                                        int forward, double* __restrict__ out) {
+  __shared__ double red[3][8][33];
   const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
-  const int col = blockIdx.x * 32 + c;
+  const int col = blockIdx.x * 32 + c, sl = blockIdx.y;
+  const int per = (R + BN_SLICES - 1) / BN_SLICES;
+  const int r0 = sl * per, r1 = (r0 + per < R) ? r0 + per : R;
   const bool ok = col < N;
-  double s = 0.0;
+  double a = 0.0, b = 0.0, n = 0.0;
   if (ok)
-    for (int i = g; i < R2; i += 32) s += (double)ws_sum[(size_t)i * N + col];
-  red[g][c] = s;
-  __syncthreads();
-  if (g == 0) {
-    double t = 0.0;
-    for (int j = 0; j < 32; ++j) t += red[j][c];
-    mu_s[c] = t / (double)P;
-  }
-  __syncthreads();
-  const double mu = mu_s[c];
-  double m2 = 0.0;
-  if (ok)
-    for (int i = g; i < R2; i += 32) {
-      int n = P - i * tile_rows;
-      n = n > tile_rows ? tile_rows : n;
-      if (n <= 0) continue;
-      const double mi = (double)ws_sum[(size_t)i * N + col] / (double)n;
-      const double d = mi - mu;
-      m2 += (double)ws_m2[(size_t)i * N + col] + d * d * (double)n;
+    for (int i = r0 + g; i < r1; i += 8) {
+      a += (double)ws_a[(size_t)i * ld + col];
+      if (forward) {
+        int ni = P - i * tile_rows;
+        ni = ni > tile_rows ? tile_rows : (ni < 0 ? 0 : ni);
+        n += (double)ni;
+      } else {
+        b += (double)ws_b[(size_t)i * ld + col];
+      }
     }
+  red[0][g][c] = a; red[1][g][c] = b; red[2][g][c] = n;
   __syncthreads();
-  red[g][c] = m2;
-  __syncthreads();
+  double A = 0.0, Bs = 0.0, Nn = 0.0;
+  for (int j = 0; j < 8; ++j) { A += red[0][j][c]; Bs += red[1][j][c]; Nn += red[2][j][c]; }
+  if (forward) {
+    const double mu = Nn > 0.0 ? A / Nn : 0.0;
+    double m2 = 0.0;
+    if (ok)
+      for (int i = r0 + g; i < r1; i += 8) {
+        int ni = P - i * tile_rows;
+        ni = ni > tile_rows ? tile_rows : ni;
+        if (ni <= 0) continue;
+        const double d = (double)ws_a[(size_t)i * ld + col] / (double)ni - mu;
+        m2 += (double)ws_b[(size_t)i * ld + col] + d * d * (double)ni;
+      }
+    __syncthreads();
+    red[1][g][c] = m2;
+    __syncthreads();
+    Bs = 0.0;
+    for (int j = 0; j < 8; ++j) Bs += red[1][j][c];
+  }
   if (g == 0 && ok) {
-    double t = 0.0;
-    for (int j = 0; j < 32; ++j) t += red[j][c];
-    const double var = t / (double)P;
-    const double rstd = 1.0 / sqrt(var + (double)eps);
-    const float sc = (float)((double)gamma[col] * rstd);
-    mean_out[col] = (float)mu;
-    rstd_out[col] = (float)rstd;
-    scale_out[col] = sc;
-    shift_out[col] = (float)((double)beta[col] - mu * (double)gamma[col] * rstd);
-    if (running_mean != nullptr) {
-      const double unb = P > 1 ? t / (double)(P - 1) : var;
-      running_mean[col] = (float)((1.0 - momentum) * (double)running_mean[col] + momentum * mu);
-      running_var[col] = (float)((1.0 - momentum) * (double)running_var[col] + momentum * unb);
-    }
+    double* o = out + ((size_t)sl * 3) * N;
+    o[col] = forward ? Nn : A;
+    o[(size_t)N + col] = forward ? A : Bs;
+    o[(size_t)2 * N + col] = forward ? Bs : 0.0;
   }
-  if (nbt != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
+}
+
+// forward stage 2: combine slice records (n, sum, M2) -> mean, rstd, scale, shift and the
+// running-stat update of nn.BatchNorm1d (momentum, UNBIASED variance)
+__global__ void bn_fwd_finalize_kernel(const double* __restrict__ sl, int P, int N,
+                                       const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, float* running_mean,
+                                       float* running_var, int64_t* nbt, float momentum, float eps,
+                                       float* mean_out, float* rstd_out, float* scale_out,
+                                       float* shift_out) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (nbt != nullptr && col == 0) *nbt += 1;
+  if (col >= N) return;
+  double n = 0.0, mean = 0.0, m2 = 0.0;
+  for (int s = 0; s < BN_SLICES; ++s) {
+    const double* r = sl + ((size_t)s * 3) * N;
+    const double ns = r[col];
+    if (ns <= 0.0) continue;
+    const double ms = r[(size_t)N + col] / ns, d = ms - mean, nt = n + ns;
+    m2 += r[(size_t)2 * N + col] + d * d * n * ns / nt;
+    mean += d * ns / nt;
+    n = nt;
+  }
+  const double var = m2 / (double)P;
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  mean_out[col] = (float)mean;
+  rstd_out[col] = (float)rstd;
+  scale_out[col] = (float)((double)gamma[col] * rstd);
+  shift_out[col] = (float)((double)beta[col] - mean * (double)gamma[col] * rstd);
+  if (running_mean != nullptr) {
+    const double unb = P > 1 ? m2 / (double)(P - 1) : var;
+    running_mean[col] = (float)((1.0 - momentum) * (double)running_mean[col] + momentum * mean);
+    running_var[col] = (float)((1.0 - momentum) * (double)running_var[col] + momentum * unb);
+  }
 }
 
 // eval-mode coefficients from running statistics
@@ -84,53 +119,38 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
   shift_out[c] = beta[c] - rm[c] * sc;
 }
 
-// ---------------------------------------------------------------------------------------
-// BatchNorm backward statistics.  Partials: ws_a[i][c] = sum dy, ws_b[i][c] = sum dy*z over
-// a 64-row tile (dy already ReLU-masked).  Produces
+// backward stage 2: Sdy, Sdyz ->
 //   dgamma = (Sdyz - mean*Sdy)*rstd, dbeta = Sdy
 //   coefficients of dz = ca*dy + cb*z + cc  (train: full BN backward; eval: ca=scale, 0, 0)
 //   db (bias of the conv ahead of the BN) = sum dz = ca*Sdy + cb*P*mean + cc*P
-// grid = ceil(N/32), block 1024.
-// ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(
-    const float* __restrict__ ws_a, const float* __restrict__ ws_b, int R2, long ws_ld, int P, int N,
-    const float* __restrict__ gamma, const float* __restrict__ mean,
-    const float* __restrict__ rstd, int training, float* ca, float* cb, float* cc,
-    float* dgamma, float* dbeta, float* dbias) {
-  __shared__ double red[2][32][33];
-  const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
-  const int col = blockIdx.x * 32 + c;
-  const bool ok = col < N;
-  double s1 = 0.0, s2 = 0.0;
-  if (ok)
-    for (int i = g; i < R2; i += 32) {
-      s1 += (double)ws_a[(size_t)i * ws_ld + col];      // ws may be a column block of a wider
-      s2 += (double)ws_b[(size_t)i * ws_ld + col];      // partial array (row stride ws_ld)
-    }
-  red[0][g][c] = s1;
-  red[1][g][c] = s2;
-  __syncthreads();
-  if (g == 0 && ok) {
-    double Sdy = 0.0, Sdyz = 0.0;
-    for (int j = 0; j < 32; ++j) {
-      Sdy += red[0][j][c];
-      Sdyz += red[1][j][c];
-    }
-    const double mu = mean[col], rs = rstd[col], gm = gamma[col];
-    const double dg = (Sdyz - mu * Sdy) * rs;
-    if (dgamma != nullptr) dgamma[col] = (float)dg;
-    if (dbeta != nullptr) dbeta[col] = (float)Sdy;
-    double a = gm * rs, b = 0.0, cst = 0.0;
-    if (training) {
-      const double m1 = Sdy / (double)P, m2 = dg / (double)P;
-      b = -a * m2 * rs;
-      cst = a * (m2 * mu * rs - m1);
-    }
-    ca[col] = (float)a;
-    cb[col] = (float)b;
-    cc[col] = (float)cst;
-    if (dbias != nullptr) dbias[col] = (float)(a * Sdy + b * (double)P * mu + cst * (double)P);
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ sl, int P, int N,
+                                       const float* __restrict__ gamma,
+                                       const float* __restrict__ mean,
+                                       const float* __restrict__ rstd, int training, float* ca,
+                                       float* cb, float* cc, float* dgamma, float* dbeta,
+                                       float* dbias) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= N) return;
+  double Sdy = 0.0, Sdyz = 0.0;
+  for (int s = 0; s < BN_SLICES; ++s) {
+    const double* r = sl + ((size_t)s * 3) * N;
+    Sdy += r[col];
+    Sdyz += r[(size_t)N + col];
   }
+  const double mu = mean[col], rs = rstd[col], gm = gamma[col];
+  const double dg = (Sdyz - mu * Sdy) * rs;
+  if (dgamma != nullptr) dgamma[col] = (float)dg;
+  if (dbeta != nullptr) dbeta[col] = (float)Sdy;
+  double a = gm * rs, b = 0.0, cst = 0.0;
+  if (training) {
+    const double m1 = Sdy / (double)P, m2 = dg / (double)P;
+    b = -a * m2 * rs;
+    cst = a * (m2 * mu * rs - m1);
+  }
+  ca[col] = (float)a;
+  cb[col] = (float)b;
+  cc[col] = (float)cst;
+  if (dbias != nullptr) dbias[col] = (float)(a * Sdy + b * (double)P * mu + cst * (double)P);
 }
 
 // plain reduction of two partial arrays over tiles: out_a[c] = sum_i ws_a[i][c] etc.

@@ -330,6 +330,7 @@ struct StackWS {
   float* w0pad = nullptr;   // [cout0, cin0p]
   float* ws_a = nullptr;    // stats partials [stat_tiles_max][maxc]
   float* ws_b = nullptr;
+  double* stat2 = nullptr;  // stage-1 slice records [BN_SLICES][3][maxc]
   char* wprep = nullptr;    // split-bf16 weight image of the layer being run
 };
 inline size_t wprep_floats(const prh_bn_layer* ly, int L, int extra_n, int extra_k) {
@@ -348,18 +349,21 @@ bool stack_ws_carve(Arena& a, StackWS& w, int P, const prh_bn_layer* ly, int L, 
   if (d.cin0p != d.cin0) { w.xpad = a.f((size_t)P * d.cin0p); w.w0pad = a.f((size_t)ly[0].cout * d.cin0p); }
   w.ws_a = a.f((size_t)stat_tiles_max(P) * maxc);
   w.ws_b = a.f((size_t)stat_tiles_max(P) * maxc);
+  w.stat2 = (double*)a.f((size_t)BN_SLICES * 3 * maxc * 2);
   w.wprep = (char*)a.f(wprep_floats(ly, L, extra_n, extra_k));
   return a.ok;
 }
 
 int bn_coeffs(const prh_bn_layer& ly, int P, int training, float momentum, float eps,
-              const float* ws_a, const float* ws_b, StatInfo si, float* mean, float* rstd,
-              float* scale, float* shift, hipStream_t st) {
+              const float* ws_a, const float* ws_b, double* stat2, StatInfo si, float* mean,
+              float* rstd, float* scale, float* shift, hipStream_t st) {
   if (training) {
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(cdiv(ly.cout, 32)), dim3(1024), 0, st, ws_a,
-                       ws_b, si.count, si.rows, P, ly.cout, ly.gamma, ly.beta, ly.running_mean,
-                       ly.running_var, ly.num_batches_tracked, momentum, eps, mean, rstd, scale,
-                       shift);
+    hipLaunchKernelGGL(bn_stage1_kernel, dim3(cdiv(ly.cout, 32), BN_SLICES), dim3(256), 0, st, ws_a,
+                       ws_b, si.count, (long)ly.cout, ly.cout, si.rows, P, 1, stat2);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(cdiv(ly.cout, 128)), dim3(128), 0, st, stat2, P,
+                       ly.cout, ly.gamma, ly.beta, ly.running_mean, ly.running_var,
+                       ly.num_batches_tracked, momentum, eps, mean, rstd, scale, shift);
   } else {
     hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(cdiv(ly.cout, 256)), dim3(256), 0, st, ly.gamma,
                        ly.beta, ly.running_mean, ly.running_var, eps, ly.cout, mean, rstd, scale,
@@ -396,7 +400,7 @@ int stack_forward(const prh_bn_layer* ly, int L, const float* x, int P, int trai
       if (training) TRY((launch_nt<PRO_BNRELU, EPI_BIAS_STATS>(p, st, &si)));
       else TRY((launch_nt<PRO_BNRELU, EPI_BIAS>(p, st)));
     }
-    TRY(bn_coeffs(ly[l], P, training, momentum, eps, w.ws_a, w.ws_b, si, mean + d.off[l],
+    TRY(bn_coeffs(ly[l], P, training, momentum, eps, w.ws_a, w.ws_b, w.stat2, si, mean + d.off[l],
                   rstd + d.off[l], scale + d.off[l], shift + d.off[l], st));
   }
   return PRH_OK;
@@ -421,8 +425,11 @@ int stack_backward(const prh_bn_layer* ly, int L, const float* x, int P, int tra
   for (int l = L - 1; l >= 0; --l) {
     const int co = ly[l].cout, o = d.off[l];
     // 1. statistics -> BN-backward coefficients, dgamma, dbeta, dbias
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(co, 32)), dim3(1024), 0, st,
-                       w.ws_a + si.off, w.ws_b + si.off, si.count, si.ld ? si.ld : (long)co, P, co,
+    hipLaunchKernelGGL(bn_stage1_kernel, dim3(cdiv(co, 32), BN_SLICES), dim3(256), 0, st,
+                       w.ws_a + si.off, w.ws_b + si.off, si.count, si.ld ? si.ld : (long)co, co, 64, P,
+                       0, w.stat2);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(co, 128)), dim3(128), 0, st, w.stat2, P, co,
                        ly[l].gamma, mean + o, rstd + o, training,
                        sc.ca, sc.cb, sc.cc, gr ? gr[l].dgamma : nullptr, gr ? gr[l].dbeta : nullptr,
                        gr ? gr[l].db : nullptr);
@@ -739,7 +746,7 @@ int prh_encoder_forward(const prh_encoder_params* prm, const float* ctx, int B, 
     StatInfo si;
     if (training) TRY((launch_nt<PRO_BNRELU, EPI_BIAS_STATS>(p, st, &si)));
     else TRY((launch_nt<PRO_BNRELU, EPI_BIAS>(p, st)));
-    TRY(bn_coeffs(prm->fusion, P, training, momentum, eps, w.ws_a, w.ws_b, si, sv->bn_mean + cat,
+    TRY(bn_coeffs(prm->fusion, P, training, momentum, eps, w.ws_a, w.ws_b, w.stat2, si, sv->bn_mean + cat,
                   sv->bn_rstd + cat, sv->bn_scale + cat, sv->bn_shift + cat, st));
   }
   // intensity gate GEMM + BN/ReLU/gate combine                     src/model.py:42,51,54-55
@@ -794,8 +801,11 @@ int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B,
                      d_gfeat, sv->argmax, sv->z_fus, sv->gate, sv->bn_scale + cat,
                      sv->bn_shift + cat, P, N, od, d_fused, w.ws_a, w.ws_b);
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(od, 32)), dim3(1024), 0, st, w.ws_a, w.ws_b,
-                     cdiv(P, 64), (long)od, P, od, prm->fusion.gamma, sv->bn_mean + cat, sv->bn_rstd + cat,
+  hipLaunchKernelGGL(bn_stage1_kernel, dim3(cdiv(od, 32), BN_SLICES), dim3(256), 0, st, w.ws_a, w.ws_b,
+                     cdiv(P, 64), (long)od, od, 64, P, 0, w.stat2);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(od, 128)), dim3(128), 0, st, w.stat2, P, od,
+                     prm->fusion.gamma, sv->bn_mean + cat, sv->bn_rstd + cat,
                      training, sc.ca, sc.cb, sc.cc, gr->fusion.dgamma, gr->fusion.dbeta,
                      gr->fusion.db);
   LAUNCH_CHECK();
