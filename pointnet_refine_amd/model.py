@@ -58,31 +58,23 @@ def _lin(x, weight, bias):
 class MultiScalePointNetEncoder(nn.Module):
     """Multi-scale PointNet encoder with dual pooling (reference: src/model.py:5-62)."""
 
+    GATE_HIDDEN = 64
+
     def __init__(self, in_channel=4, out_dim=1024):
         super().__init__()
-        self.conv1 = nn.Conv1d(in_channel, 64, 1)
-        self.conv2 = nn.Conv1d(64, 128, 1)
-        self.conv3 = nn.Conv1d(128, 256, 1)
-        self.conv4 = nn.Conv1d(256, 512, 1)
-        self.conv5 = nn.Conv1d(512, out_dim, 1)
-        self.bn1 = nn.BatchNorm1d(64)
-        self.bn2 = nn.BatchNorm1d(128)
-        self.bn3 = nn.BatchNorm1d(256)
-        self.bn4 = nn.BatchNorm1d(512)
-        self.bn5 = nn.BatchNorm1d(out_dim)
-        self.fusion = nn.Sequential(
-            nn.Conv1d(64 + 128 + 256 + 512 + out_dim, out_dim, 1),
-            nn.BatchNorm1d(out_dim),
-            nn.ReLU(),
-        )
-        self.intensity_gate = nn.Sequential(
-            nn.Conv1d(1, 64, 1),
-            nn.ReLU(),
-            nn.Conv1d(64, out_dim, 1),
-            nn.Sigmoid(),
-        )
-        self.in_channel = in_channel
-        self.out_dim = out_dim
+        # Parameter containers only (names, shapes, default initialisers and registration
+        # order of the reference's state_dict); the kernels read their tensors directly.
+        widths = (in_channel, 64, 128, 256, 512, out_dim)
+        for k in range(1, 6):
+            self.add_module(f"conv{k}", nn.Conv1d(widths[k - 1], widths[k], kernel_size=1))
+        for k in range(1, 6):
+            self.add_module(f"bn{k}", nn.BatchNorm1d(widths[k]))
+        self.fusion = nn.Sequential(nn.Conv1d(sum(widths[1:]), out_dim, kernel_size=1),
+                                    nn.BatchNorm1d(out_dim), nn.ReLU())
+        self.intensity_gate = nn.Sequential(nn.Conv1d(1, self.GATE_HIDDEN, kernel_size=1), nn.ReLU(),
+                                            nn.Conv1d(self.GATE_HIDDEN, out_dim, kernel_size=1),
+                                            nn.Sigmoid())
+        self.in_channel, self.out_dim = in_channel, out_dim
 
     def _param_list(self):
         sd = dict(self.named_parameters())
@@ -131,33 +123,30 @@ class DetrTransformerDecoderLayer(nn.Module):
 
     def __init__(self, d_model=256, nhead=8, dim_feedforward=1024, dropout=0.1):
         super().__init__()
-        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout, batch_first=True)
-        self.cross_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout, batch_first=True)
+        # containers in the reference's registration order (state_dict keys self_attn.*,
+        # cross_attn.*, linear1/2.*, norm1..3.*); nn.MultiheadAttention only stores the packed
+        # in_proj / out_proj parameters here, its forward is never called
+        for name in ("self_attn", "cross_attn"):
+            self.add_module(name, nn.MultiheadAttention(d_model, nhead, dropout=dropout, batch_first=True))
         self.linear1 = nn.Linear(d_model, dim_feedforward)
         self.dropout = nn.Dropout(dropout)
         self.linear2 = nn.Linear(dim_feedforward, d_model)
-        self.norm1 = nn.LayerNorm(d_model)
-        self.norm2 = nn.LayerNorm(d_model)
-        self.norm3 = nn.LayerNorm(d_model)
-        self.dropout1 = nn.Dropout(dropout)
-        self.dropout2 = nn.Dropout(dropout)
-        self.dropout3 = nn.Dropout(dropout)
+        for k in (1, 2, 3):
+            self.add_module(f"norm{k}", nn.LayerNorm(d_model))
+        for k in (1, 2, 3):
+            self.add_module(f"dropout{k}", nn.Dropout(dropout))
         self.activation = F.relu
 
     def with_pos_embed(self, tensor, pos):
         return tensor if pos is None else tensor + pos
 
     def forward(self, tgt, memory, query_pos=None, pos=None):
-        q = k = self.with_pos_embed(tgt, query_pos)
-        tgt2 = self.self_attn(q, k, value=tgt)[0]
-        tgt = self.norm1(tgt + self.dropout1(tgt2))
-        q = self.with_pos_embed(tgt, query_pos)
-        k = self.with_pos_embed(memory, pos)
-        tgt2 = self.cross_attn(q, k, value=memory)[0]
-        tgt = self.norm2(tgt + self.dropout2(tgt2))
-        tgt2 = self.linear2(self.dropout(self.activation(self.linear1(tgt))))
-        tgt = self.norm3(tgt + self.dropout3(tgt2))
-        return tgt
+        """The reference's call contract (src/model.py:103-135): projects this layer's keys
+        (memory + pos) and values (memory) on the HIP GEMM cores and runs the shared body."""
+        ca, d = self.cross_attn, self.cross_attn.embed_dim
+        k_proj = _lin(self.with_pos_embed(memory, pos), ca.in_proj_weight[d:2 * d], ca.in_proj_bias[d:2 * d])
+        v_proj = _lin(memory, ca.in_proj_weight[2 * d:], ca.in_proj_bias[2 * d:])
+        return self.forward_projected(tgt, k_proj, v_proj, query_pos=query_pos)
 
     def forward_projected(self, tgt, k_proj, v_proj, query_pos=None, kv_block=None):
         """Same layer with the cross-attention key/value projections already applied
@@ -195,25 +184,24 @@ class LineRefineNet(nn.Module):
     (6,B,M,3) cumulative offsets per decoder layer."""
 
     def __init__(self, num_line_points=32, feature_dim=1024):
-        super().__init__()
-        self.d_model = 256
-        self.num_decoder_layers = 6
+        super().__init__()                         # num_line_points: accepted and unused, as in the reference
+        d = self.d_model = 256
+        L = self.num_decoder_layers = 6
         self.context_encoder = MultiScalePointNetEncoder(in_channel=4, out_dim=feature_dim)
-        self.context_proj = nn.Linear(feature_dim, self.d_model)
-        self.point_mlp = nn.Sequential(
-            nn.Conv1d(3, 64, 1), nn.BatchNorm1d(64), nn.ReLU(),
-            nn.Conv1d(64, 128, 1), nn.BatchNorm1d(128), nn.ReLU(),
-            nn.Conv1d(128, self.d_model, 1), nn.BatchNorm1d(self.d_model),
-        )
-        self.pos_emb = PositionalEncoding(in_dim=3, out_dim=self.d_model)
-        self.decoder_layers = nn.ModuleList([
-            DetrTransformerDecoderLayer(d_model=self.d_model, nhead=8, dim_feedforward=1024)
-            for _ in range(self.num_decoder_layers)
-        ])
-        self.reg_branches = nn.ModuleList([
-            nn.Sequential(nn.Linear(self.d_model, 128), nn.ReLU(), nn.Linear(128, 3))
-            for _ in range(self.num_decoder_layers)
-        ])
+        self.context_proj = nn.Linear(feature_dim, d)
+        # line encoder 3 -> 64 -> 128 -> 256: conv+BN pairs, ReLU after the first two only
+        # (Sequential indices 0/1, 3/4, 6/7 as in the reference's state_dict)
+        stack, widths = [], (3, 64, 128, d)
+        for k in range(1, 4):
+            stack += [nn.Conv1d(widths[k - 1], widths[k], kernel_size=1), nn.BatchNorm1d(widths[k])]
+            if k < 3:
+                stack.append(nn.ReLU())
+        self.point_mlp = nn.Sequential(*stack)
+        self.pos_emb = PositionalEncoding(in_dim=3, out_dim=d)
+        self.decoder_layers = nn.ModuleList(
+            DetrTransformerDecoderLayer(d_model=d, nhead=8, dim_feedforward=1024) for _ in range(L))
+        self.reg_branches = nn.ModuleList(
+            nn.Sequential(nn.Linear(d, 128), nn.ReLU(), nn.Linear(128, 3)) for _ in range(L))
 
     # -- accelerated rows -------------------------------------------------------------------
     def encode_context(self, context):

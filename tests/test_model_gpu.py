@@ -212,3 +212,34 @@ def test_config2_fwd_bwd_two_kernel_families_agree():
     assert worst < 2e-3, worst
     for k, v in res[0][2].items():
         assert maxdiff(v, res[1][2][k]) <= 1e-5 * float(v.abs().max()) + 1e-7, k
+
+
+def test_decoder_layer_standalone_call_contract():
+    """DetrTransformerDecoderLayer(tgt, memory, query_pos, pos) — the reference's own call
+    signature (src/model.py:103) — against the oracle's decoder_layer, forward and backward."""
+    from pointnet_refine_amd.model import DetrTransformerDecoderLayer
+    torch.manual_seed(5)
+    layer = DetrTransformerDecoderLayer(d_model=256, nhead=8, dim_feedforward=1024, dropout=0.0).cuda().train()
+    B, M, N = 3, 32, 192
+    tgt = torch.randn(B, M, 256, device="cuda", requires_grad=True)
+    mem = torch.randn(B, N, 256, device="cuda", requires_grad=True)
+    qp = torch.randn(B, M, 256, device="cuda")
+    pp = torch.randn(B, N, 256, device="cuda")
+    w = torch.randn(B, M, 256, device="cuda")
+    out = layer(tgt, mem, query_pos=qp, pos=pp)
+    (out * w).sum().backward()
+
+    p = {"L." + k: v.detach().double().cpu().requires_grad_(True) for k, v in layer.state_dict().items()}
+    t2 = tgt.detach().double().cpu().requires_grad_(True)
+    m2 = mem.detach().double().cpu().requires_grad_(True)
+    ref = O.decoder_layer(p, "L", t2, m2, qp.double().cpu(), pp.double().cpu())
+    (ref * w.double().cpu()).sum().backward()
+    assert maxdiff(out, ref) < 1e-4
+    assert rel_l2(tgt.grad, t2.grad) < 1e-4
+    assert rel_l2(mem.grad, m2.grad) < 1e-4
+    for k, v in layer.named_parameters():
+        assert rel_l2(v.grad, p["L." + k].grad) < 1e-4, k
+    # pos / query_pos may be omitted (with_pos_embed(None))
+    out2 = layer(tgt, mem)
+    ref2 = O.decoder_layer(p, "L", t2, m2, torch.zeros_like(t2), torch.zeros_like(m2))
+    assert maxdiff(out2, ref2) < 1e-4
