@@ -55,7 +55,9 @@ struct NTParams {
   float* ws_a; float* ws_b;      // stats partials [2*row_tiles][N]
   int flags;
   int tiles_n;
-  char* wprep;                   // scratch for the split-bf16 weight image (null: fp32 MFMA core)
+  char* wprep;                   // scratch for the split weight image (null: fp32 MFMA core)
+  const float* amaxA;            // fp16-plane cores: largest |pro(A)| (device; null: the launch
+  const float* amaxW;            //   measures it) and largest |W| (set by the launch)
 };
 
 constexpr int BM = 128, BN = 128, BK = 32;
@@ -449,6 +451,8 @@ struct TNParams {
   float* colsum;      // [splits][Mo] column sums of proA(A), or null
   int splits; int rows_per_split;
   int tiles_m, tiles_n;
+  const float* amaxA;            // fp16-plane core: largest |proA(A)|, |proB(B)| (device; null:
+  const float* amaxB;            //   the launch measures them)
 };
 
 template <int PROA, int PROB>

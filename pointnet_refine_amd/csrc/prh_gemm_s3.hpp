@@ -58,13 +58,95 @@ __device__ __forceinline__ void split2(float a0, float a1, unsigned& h, unsigned
 }
 
 // ---------------------------------------------------------------------------------------
+// NPL = 2: two fp16 planes and three products.  fp16 carries 11 significant bits, so
+//     a*S = h + l   (h = fp16(a*S), l = fp16(a*S - h): 22 bits)
+//     a*w = (h*h' + h*l' + l*h') / (S*S')          (dropped: l*l' <= 2^-22)
+// has a split error of ~7e-8 relative (numpy emulation), below the error of the
+// fp32 accumulation itself, for HALF the MFMA issue of the six-product bf16 form.  fp16 has a
+// narrow exponent, so each operand carries a power-of-two scale S chosen from its largest
+// magnitude (absmax_kernel below; the result is unscaled exactly in the epilogue):
+// amax*S lies in [2^13, 2^14), a factor 4 under the fp16 maximum; elements down to 2^-16 of
+// the largest keep all 22 bits, smaller ones degrade gracefully (absolute floor 2^-25 * S^-1).
+// ---------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float pow2_scale(float amax) {
+  const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu);   // biased exponent, amax >= 0
+  if (e == 0 || e == 255) return 1.f;                            // 0 / denormal / inf / nan
+  int se = 127 + 13 - (e - 127);
+  se = se < 67 ? 67 : (se > 187 ? 187 : se);                     // S within 2^-60 .. 2^60
+  return __uint_as_float((unsigned)se << 23);
+}
+
+// split two (already scaled) floats into packed fp16 pairs (h, l)
+__device__ __forceinline__ void split2h(float a0, float a1, unsigned& h, unsigned& l) {
+  f32x2 v = {a0, a1};
+  f16x2 hb = __builtin_convertvector(v, f16x2);
+  h = *reinterpret_cast<unsigned*>(&hb);
+  f32x2 r = {a0 - (float)hb[0], a1 - (float)hb[1]};
+  f16x2 lb = __builtin_convertvector(r, f16x2);
+  l = *reinterpret_cast<unsigned*>(&lb);
+}
+
+// Largest magnitude of pro(A) over [rows, cols] -> atomic max on *out (float bits of a
+// non-negative value order like unsigned integers; *out is zeroed by the host).  One pass at
+// HBM rate: block = 64 column vectors x 4 rows, a thread keeps its column's prologue
+// coefficients in registers and walks down the rows (no per-element index arithmetic).
+// vec = 1: cols and the leading dimensions are multiples of 4 (16-B loads).
+template <int PRO>
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ A, long lda,
+                                                     const float* __restrict__ A2, long lda2,
+                                                     const float* __restrict__ pa,
+                                                     const float* __restrict__ pb,
+                                                     const float* __restrict__ pc, long rows,
+                                                     int cols, int vec, unsigned* __restrict__ out) {
+  float m = 0.f;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long r0 = (long)blockIdx.x * 4 + ty, rstep = (long)gridDim.x * 4;
+  if (vec) {
+    const int c4 = cols >> 2;
+    for (int cv = tx; cv < c4; cv += 64) {
+      const int c = cv * 4;
+      float4 ka = zero4(), kb = zero4(), kc = zero4();
+      if (PRO != PRO_NONE) { ka = ldg4(pa + c); kb = ldg4(pb + c); }
+      if (PRO == PRO_BNBWD) kc = ldg4(pc + c);
+#pragma unroll 4
+      for (long r = r0; r < rows; r += rstep) {
+        const float4 a = PRO == PRO_GATE1 ? make_float4(A[r * lda], 0.f, 0.f, 0.f) : ldg4(A + r * lda + c);
+        const float4 a2 = PRO == PRO_BNBWD ? ldg4(A2 + r * lda2 + c) : zero4();
+        const float4 v = pro_apply<PRO>(a, a2, ka, kb, kc);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+      }
+    }
+  } else {
+    for (int c = tx; c < cols; c += 64) {
+      float ka = 0.f, kb = 0.f, kc = 0.f;
+      if (PRO != PRO_NONE) { ka = pa[c]; kb = pb[c]; }
+      if (PRO == PRO_BNBWD) kc = pc[c];
+      for (long r = r0; r < rows; r += rstep) {
+        float x = PRO == PRO_GATE1 ? A[r * lda] : A[r * lda + c];
+        if (PRO == PRO_BNRELU || PRO == PRO_GATE1) x = fmaxf(fmaf(x, ka, kb), 0.f);
+        if (PRO == PRO_BNBWD) x = fmaf(ka, x, fmaf(kb, A2[r * lda2 + c], kc));
+        m = fmaxf(m, fabsf(x));
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if (tx == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+
+// ---------------------------------------------------------------------------------------
 // Weight preparation: W'[n][k] (= W[n*ldw + k], or W[k*ldw + n] when transposed) ->
 // tiled planes out[((n_tile*KT + k_tile)*3 + plane) * 8 KB + s3_off(row, k)], zero padded.
 // One thread per (row, 8-k chunk).
 // ---------------------------------------------------------------------------------------
+// amax != null: two-plane fp16 image of W * pow2_scale(*amax) (planes 0 and 1)
 __global__ __launch_bounds__(256) void prep_weights_s3_kernel(const float* __restrict__ W, int N,
                                                               int K, long ldw, int transposed,
-                                                              char* __restrict__ out) {
+                                                              char* __restrict__ out,
+                                                              const float* __restrict__ amax) {
   const int KT = (K + S3_BK - 1) / S3_BK;
   const int NT_ = (N + S3_BN - 1) / S3_BN;
   const long total = (long)NT_ * 256 * KT * 2;
@@ -83,18 +165,29 @@ __global__ __launch_bounds__(256) void prep_weights_s3_kernel(const float* __res
     v[j] = (n < N && k < K) ? (transposed ? W[(size_t)k * ldw + n] : W[(size_t)n * ldw + k]) : 0.f;
   }
   uint4 h, m, l;
+  char* base = out + ((size_t)n_tile * KT + k_tile) * S3_OPER + s3_off(row, chunk * 8);
+  if (amax != nullptr) {
+    const float S = pow2_scale(*amax);
+    split2h(v[0] * S, v[1] * S, h.x, l.x);
+    split2h(v[2] * S, v[3] * S, h.y, l.y);
+    split2h(v[4] * S, v[5] * S, h.z, l.z);
+    split2h(v[6] * S, v[7] * S, h.w, l.w);
+    *reinterpret_cast<uint4*>(base) = h;
+    *reinterpret_cast<uint4*>(base + S3_PLANE) = l;
+    return;
+  }
   split2(v[0], v[1], h.x, m.x, l.x);
   split2(v[2], v[3], h.y, m.y, l.y);
   split2(v[4], v[5], h.z, m.z, l.z);
   split2(v[6], v[7], h.w, m.w, l.w);
-  char* base = out + ((size_t)n_tile * KT + k_tile) * S3_OPER + s3_off(row, chunk * 8);
   *reinterpret_cast<uint4*>(base) = h;
   *reinterpret_cast<uint4*>(base + S3_PLANE) = m;
   *reinterpret_cast<uint4*>(base + 2 * S3_PLANE) = l;
 }
 
+constexpr int S3_WHDR = 256;   // head of a weight image: [0] largest |W|, [1] largest |pro(A)| (floats)
 inline size_t s3_weight_bytes(int N, int K) {
-  return (size_t)((N + S3_BN - 1) / S3_BN) * ((K + S3_BK - 1) / S3_BK) * S3_OPER;
+  return S3_WHDR + (size_t)((N + S3_BN - 1) / S3_BN) * ((K + S3_BK - 1) / S3_BK) * S3_OPER;
 }
 
 // LDS-DMA of 16 B per lane, hidden from the compiler's wait-count bookkeeping: with the builtin
@@ -129,6 +222,28 @@ __device__ __forceinline__ void mfma6(f32x16& acc, const bf16x8& ah, const bf16x
 template <int NPL, int I0 = 0, int I1 = 4>
 __device__ __forceinline__ void s3_compute(f32x16 (&acc)[4][2], const char* st, int wm, int wn,
                                            int l31, int half) {
+  if constexpr (NPL == 2) {      // fp16 planes (h, l): l*h' + h*l' + h*h'
+    f16x8 w[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const char* q = st + S3_OPER + s3_off(wn + j * 32 + l31, half * 8);
+      w[j][0] = *reinterpret_cast<const f16x8*>(q);
+      w[j][1] = *reinterpret_cast<const f16x8*>(q + S3_PLANE);
+    }
+#pragma unroll
+    for (int i = I0; i < I1; ++i) {
+      const char* q = st + s3_off(wm + i * 32 + l31, half * 8);
+      const f16x8 ah = *reinterpret_cast<const f16x8*>(q);
+      const f16x8 al = *reinterpret_cast<const f16x8*>(q + S3_PLANE);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, w[j][0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w[j][1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, w[j][0], acc[i][j], 0, 0, 0);
+      }
+    }
+    return;
+  }
   bf16x8 w[2][NPL];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -157,6 +272,9 @@ template <int NPL>
 __device__ __forceinline__ void splitn(float a0, float a1, unsigned& h, unsigned& m, unsigned& l) {
   if constexpr (NPL == 3) {
     split2(a0, a1, h, m, l);
+  } else if constexpr (NPL == 2) {
+    split2h(a0, a1, h, m);
+    l = 0;
   } else {
     f32x2 v = {a0, a1};
     bf16x2 hb = __builtin_convertvector(v, bf16x2);
@@ -185,6 +303,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
   const int sr = tid >> 2;           // staging row 0..127 (+128)
   const int KP = (KT + 2) * S3_BK;   // padded length of the coefficient vectors in LDS
   float* coef = reinterpret_cast<float*>(smem + S3_LDS);
+  // fp16 planes: operand scales (powers of two), folded into the prologue coefficients
+  float sA = 1.f, unscale = 1.f;
+  if (NPL == 2) {
+    sA = pow2_scale(*p.amaxA);
+    unscale = 1.f / (sA * pow2_scale(*p.amaxW));
+  }
 
   f32x16 acc[4][2];
 #pragma unroll
@@ -265,15 +389,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
       if (PRO == PRO_GATE1) v = pro_apply<PRO>(make_float4(gi[j], 0.f, 0.f, 0.f), zero4(), ka, kb, kc);
       else v = pro_apply<PRO>(r_[j], r2_[j], ka, kb, kc);
       v.x = kok ? v.x : 0.f; v.y = kok ? v.y : 0.f; v.z = kok ? v.z : 0.f; v.w = kok ? v.w : 0.f;
+      if (NPL == 2 && PRO == PRO_NONE) { v.x *= sA; v.y *= sA; v.z *= sA; v.w *= sA; }
       uint2 h, m, l;
       splitn<NPL>(v.x, v.y, h.x, m.x, l.x);
       splitn<NPL>(v.z, v.w, h.y, m.y, l.y);
       char* q = st + s3_off(r, sc);
       *reinterpret_cast<uint2*>(q) = h;
-      if (NPL == 3) {
-        *reinterpret_cast<uint2*>(q + S3_PLANE) = m;
-        *reinterpret_cast<uint2*>(q + 2 * S3_PLANE) = l;
-      }
+      if (NPL >= 2) *reinterpret_cast<uint2*>(q + S3_PLANE) = m;
+      if (NPL == 3) *reinterpret_cast<uint2*>(q + 2 * S3_PLANE) = l;
     }
   };
   // one k-tile: compute tile kt from its stage, convert tile kt+1 out of register set CS into
@@ -315,6 +438,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
       }
+    } else if constexpr (NPL == 2) {
+#pragma unroll
+      for (int g = 0; g < 24; ++g) {      // 24 MFMAs, ~70 conversion VALU per k-tile
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+      }
     }
     // the DMA of this k-tile (older than its NA register loads) must have landed
     asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NA) : "memory");
@@ -331,9 +460,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
     // slack for the prefetch distance
     for (int i = tid; i < KP; i += 512) {
       const bool in = i < p.K;
-      coef[i] = in ? p.pa[i] : 0.f;
-      coef[KP + i] = in ? p.pb[i] : 0.f;
-      if (PRO == PRO_BNBWD) coef[2 * KP + i] = in ? p.pc[i] : 0.f;
+      coef[i] = in ? p.pa[i] * sA : 0.f;      // every prologue is positively homogeneous in its coefficients
+      coef[KP + i] = in ? p.pb[i] * sA : 0.f;
+      if (PRO == PRO_BNBWD) coef[2 * KP + i] = in ? p.pc[i] * sA : 0.f;
     }
     __syncthreads();
   }
@@ -348,6 +477,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
   if (kt < KT) iter(kt, std::integral_constant<int, 1>{});
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (NPL == 2) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] *= unscale;
+  }
   // the stage buffers are free now (every DMA drained, every wave past its last fragment read):
   // use them as wave-private scratch for the row-major, 16-B-per-lane epilogue
   const bool vec_ok = ((p.N | (int)p.ldc) & 3) == 0 && (p.E1 == nullptr || ((int)p.lde1 & 3) == 0) &&
@@ -395,6 +532,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_s3_kernel(const TNParams p) {
   if (PROB != PRO_NONE && bok) {
     qa = p.qa[n0 + c];
     qb = p.qb[n0 + c];
+  }
+  // fp16 planes: operand scales (powers of two) folded into the per-column coefficients
+  float sA = 1.f, sB = 1.f;
+  if (NPL == 2) {
+    sA = pow2_scale(*p.amaxA);
+    sB = pow2_scale(*p.amaxB);
+    ka *= sA; kb *= sA; kc *= sA; qa *= sB; qb *= sB;
   }
 
   f32x16 acc[4][2];
@@ -448,9 +592,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_s3_kernel(const TNParams p) {
       float x = xa[j];
       if (PROA == PRO_BNBWD) x = fmaf(ka, xa[j], fmaf(kb, xa2[j], kc));
       else if (PROA == PRO_BNRELU) x = fmaxf(fmaf(xa[j], ka, kb), 0.f);
+      else if (NPL == 2) x *= sA;
       ta[j] = (rok && aok) ? x : 0.f;
       float y = xb[j];
       if (PROB == PRO_BNRELU) y = fmaxf(fmaf(xb[j], qa, qb), 0.f);
+      else if (NPL == 2) y *= sB;
       tb[j] = (rok && bok) ? y : 0.f;
       csum += ta[j];
     }
@@ -461,20 +607,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_s3_kernel(const TNParams p) {
     splitn<NPL>(ta[6], ta[7], h.w, m.w, l.w);
     char* q = st + s3_off(c, oct * 8);
     *reinterpret_cast<uint4*>(q) = h;
-    if (NPL == 3) {
-      *reinterpret_cast<uint4*>(q + S3_PLANE) = m;
-      *reinterpret_cast<uint4*>(q + 2 * S3_PLANE) = l;
-    }
+    if (NPL >= 2) *reinterpret_cast<uint4*>(q + S3_PLANE) = m;
+    if (NPL == 3) *reinterpret_cast<uint4*>(q + 2 * S3_PLANE) = l;
     splitn<NPL>(tb[0], tb[1], h.x, m.x, l.x);
     splitn<NPL>(tb[2], tb[3], h.y, m.y, l.y);
     splitn<NPL>(tb[4], tb[5], h.z, m.z, l.z);
     splitn<NPL>(tb[6], tb[7], h.w, m.w, l.w);
     q += S3_OPER;
     *reinterpret_cast<uint4*>(q) = h;
-    if (NPL == 3) {
-      *reinterpret_cast<uint4*>(q + S3_PLANE) = m;
-      *reinterpret_cast<uint4*>(q + 2 * S3_PLANE) = l;
-    }
+    if (NPL >= 2) *reinterpret_cast<uint4*>(q + S3_PLANE) = m;
+    if (NPL == 3) *reinterpret_cast<uint4*>(q + 2 * S3_PLANE) = l;
   };
   // distance-1 software pipeline (a second staging register set does not fit next to the
   // 128 accumulators): loads of tile kt+1 are issued ahead of the MFMAs of tile kt and
@@ -502,9 +644,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_s3_kernel(const TNParams p) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
       }
+    } else if constexpr (NPL == 2) {
+#pragma unroll
+      for (int g = 0; g < 12; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+      }
     }
     __syncthreads();
   }
+  const float unscale = NPL == 2 ? 1.f / (sA * sB) : 1.f;
 
   float* out = p.slab + (size_t)split * p.Mo * p.Ni;
 #pragma unroll
@@ -515,7 +664,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_s3_kernel(const TNParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm + mt * 32 + crow(r, half);
-        if (row < p.Mo && col < p.Ni) out[(size_t)row * p.Ni + col] = acc[mt][nt][r];
+        if (row < p.Mo && col < p.Ni) out[(size_t)row * p.Ni + col] = acc[mt][nt][r] * unscale;
       }
     }
 
@@ -524,7 +673,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_s3_kernel(const TNParams p) {
     red[tid] = csum;
     __syncthreads();
     if (tid < 256 && (m0 + tid) < p.Mo)
-      p.colsum[(size_t)split * p.Mo + m0 + tid] = red[tid] + red[tid + 256];
+      p.colsum[(size_t)split * p.Mo + m0 + tid] = (red[tid] + red[tid + 256]) * (NPL == 2 ? 1.f / sA : 1.f);
   }
 }
 

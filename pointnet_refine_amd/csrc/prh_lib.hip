@@ -42,6 +42,14 @@ int fail(int code, const char* fmt, ...) {
   } while (0)
 
 #define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
+#define TRY_RC(x)                  \
+  do {                             \
+    int rc_ = (x);                 \
+    if (rc_ != PRH_OK) return rc_; \
+  } while (0)
+#ifndef PRH_GEMM_DEFAULT
+#define PRH_GEMM_DEFAULT 1
+#endif
 
 // ------------------------------------------------------------------ optional profiler
 // bench.py brackets every GEMM launch with HIP events ON THE LAUNCH STREAM so it can quote
@@ -92,15 +100,38 @@ struct Arena {
 // Which GEMM core serves a launch.  PRH_GEMM=fp32 forces the exact fp32 MFMA cores
 // everywhere; default "split" routes large GEMMs to the 3-plane bf16 cores (fp32-level
 // error, 2.67x higher matrix ceiling) and keeps small / odd-shaped ones on the fp32 cores.
-// -1: not initialised, 0: fp32 cores only, 1: split-bf16 (3 planes, fp32-accurate) for large
-// GEMMs, 2: plain bf16 operands (1 plane) for large GEMMs - reduced precision, opt-in only
+// -1: not initialised, 0: fp32 cores only, 1: split-bf16 (3 planes, 6 products, fp32-accurate)
+// for large GEMMs, 2: plain bf16 operands (1 plane) for large GEMMs - reduced precision,
+// opt-in only, 3: split-fp16 (2 scaled planes, 3 products, fp32-accurate) for large GEMMs
 int g_gemm_mode = -1;
 inline int gemm_mode() {
   if (g_gemm_mode < 0) {
     const char* e = getenv("PRH_GEMM");
-    g_gemm_mode = (e != nullptr && strcmp(e, "fp32") == 0) ? 0 : ((e != nullptr && strcmp(e, "bf16") == 0) ? 2 : 1);
+    g_gemm_mode = PRH_GEMM_DEFAULT;
+    if (e != nullptr && strcmp(e, "fp32") == 0) g_gemm_mode = 0;
+    else if (e != nullptr && strcmp(e, "split") == 0) g_gemm_mode = 1;
+    else if (e != nullptr && strcmp(e, "bf16") == 0) g_gemm_mode = 2;
+    else if (e != nullptr && strcmp(e, "split16") == 0) g_gemm_mode = 3;
   }
   return g_gemm_mode;
+}
+inline const char* core_tag() { return gemm_mode() == 2 ? "b1" : (gemm_mode() == 3 ? "h2" : "s3"); }
+
+// largest |pro(A)| over [rows, cols] into *slot (zeroed here)
+template <int PRO>
+int measure_absmax(const float* A, long lda, const float* A2, long lda2, const float* pa,
+                   const float* pb, const float* pc, long rows, int cols, float* slot,
+                   hipStream_t st) {
+  HIP_TRY(hipMemsetAsync(slot, 0, sizeof(float), st));
+  if (rows <= 0 || cols <= 0) return PRH_OK;
+  const int vec = ((cols & 3) == 0 && (PRO == PRO_GATE1 || (lda & 3) == 0) &&
+                   (PRO != PRO_BNBWD || (lda2 & 3) == 0)) ? 1 : 0;
+  long blocks = cdiv(rows, 4L * 8);      // >= 8 rows per thread column, at most 8 blocks per CU
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  hipLaunchKernelGGL((absmax_kernel<PRO>), dim3((unsigned)blocks), dim3(256), 0, st, A, lda, A2, lda2,
+                     pa, pb, pc, rows, cols, vec, reinterpret_cast<unsigned*>(slot));
+  LAUNCH_CHECK();
+  return PRH_OK;
 }
 inline bool split_enabled() { return gemm_mode() != 0; }
 inline bool nt_use_s3(int M, int N, int K) {
@@ -146,24 +177,39 @@ int launch_nt(NTParams p, hipStream_t st, StatInfo* si = nullptr) {
         !(EPI == EPI_GATE && ((p.N | (int)p.ldc | (int)p.lde1 | (int)p.ldc2) & 3) != 0)) {
       const int KT = cdiv(p.K, S3_BK), NTl = cdiv(p.N, S3_BN);
       const long th = (long)NTl * 256 * KT * 2;
+      const int mode = gemm_mode();
+      float* hdr = reinterpret_cast<float*>(p.wprep);
+      const char* img = p.wprep + S3_WHDR;
+      if (mode == 3) {      // operand scales of the fp16-plane core
+        TRY_RC((measure_absmax<PRO_NONE>(p.W, p.ldw, nullptr, 0, nullptr, nullptr, nullptr, p.N, p.K, hdr, st)));
+        p.amaxW = hdr;
+        if (p.amaxA == nullptr) {
+          TRY_RC((measure_absmax<PRO>(p.A, p.lda, p.A2, p.lda2, p.pa, p.pb, p.pc, p.M, p.K, hdr + 1, st)));
+          p.amaxA = hdr + 1;
+        }
+      }
       hipLaunchKernelGGL(prep_weights_s3_kernel, dim3((unsigned)cdiv(th, 256)), dim3(256), 0, st,
-                         p.W, p.N, p.K, p.ldw, 0, p.wprep);
+                         p.W, p.N, p.K, p.ldw, 0, p.wprep + S3_WHDR, mode == 3 ? (const float*)hdr : nullptr);
       LAUNCH_CHECK();
       p.tiles_n = NTl;
       const long tiles = (long)NTl * cdiv(p.M, S3_BM);
       static const int attr_rc = allow_big_lds(gemm_nt_s3_kernel<PRO, EPI, 3>);
       static const int attr_rc1 = allow_big_lds(gemm_nt_s3_kernel<PRO, EPI, 1>);
+      static const int attr_rc2 = allow_big_lds(gemm_nt_s3_kernel<PRO, EPI, 2>);
       if (attr_rc != PRH_OK) return attr_rc;
       if (attr_rc1 != PRH_OK) return attr_rc1;
-      const bool one = gemm_mode() == 2;
-      snprintf(nm, sizeof(nm), "gemm_nt_%s<%d,%d> K=%d N=%d", one ? "b1" : "s3", PRO, EPI, p.K, p.N);
+      if (attr_rc2 != PRH_OK) return attr_rc2;
+      snprintf(nm, sizeof(nm), "gemm_nt_%s<%d,%d> K=%d N=%d", core_tag(), PRO, EPI, p.K, p.N);
       ProfScope ps(nm, 2.0 * p.M * (double)p.N * p.K, by, st);
-      if (one)
+      if (mode == 2)
         hipLaunchKernelGGL((gemm_nt_s3_kernel<PRO, EPI, 1>), dim3((unsigned)tiles), dim3(512),
-                           nt_s3_lds(p.K, PRO), st, p, (const char*)p.wprep);
+                           nt_s3_lds(p.K, PRO), st, p, img);
+      else if (mode == 3)
+        hipLaunchKernelGGL((gemm_nt_s3_kernel<PRO, EPI, 2>), dim3((unsigned)tiles), dim3(512),
+                           nt_s3_lds(p.K, PRO), st, p, img);
       else
         hipLaunchKernelGGL((gemm_nt_s3_kernel<PRO, EPI, 3>), dim3((unsigned)tiles), dim3(512),
-                           nt_s3_lds(p.K, PRO), st, p, (const char*)p.wprep);
+                           nt_s3_lds(p.K, PRO), st, p, img);
       LAUNCH_CHECK();
       if (si) { si->count = 2 * cdiv(p.M, S3_BM); si->rows = 128; }
       return PRH_OK;
@@ -204,9 +250,10 @@ inline TNPlan tn_plan(int P, int Mo, int Ni, bool allow_s3) {
   pl.rows_per_split = rps;
   return pl;
 }
+constexpr int TN_HDR = 64;   // floats behind a slab: [0] largest |proA(A)|, [1] largest |proB(B)|
 inline size_t tn_slab_floats(int P, int Mo, int Ni) {   // upper bound over both cores
   const size_t a = (size_t)tn_plan(P, Mo, Ni, true).splits, b = (size_t)tn_plan(P, Mo, Ni, false).splits;
-  return (a > b ? a : b) * Mo * Ni;
+  return (a > b ? a : b) * Mo * Ni + TN_HDR;
 }
 inline size_t tn_colsum_floats(int P, int Mo, int Ni) {
   const size_t a = (size_t)tn_plan(P, Mo, Ni, true).splits, b = (size_t)tn_plan(P, Mo, Ni, false).splits;
@@ -215,8 +262,8 @@ inline size_t tn_colsum_floats(int P, int Mo, int Ni) {
 
 // C[Mo,Ni] (ld ldc) = proA(A)^T proB(B); colsum_out[Mo] = column sums of proA(A) (optional)
 template <int PROA, int PROB>
-int launch_tn(TNParams p, float* slab, float* colsum_slab, float* C, long ldc, float* colsum_out,
-              hipStream_t st) {
+int launch_tn(TNParams& p, float* slab, float* colsum_slab, float* C, long ldc, float* colsum_out,
+              hipStream_t st) {   // p.amaxA / p.amaxB are filled in when the fp16-plane core measured them
   if (p.Mo <= 0 || p.Ni <= 0) return PRH_OK;
   const bool ld_ok = p.lda <= TN_S3_MAX_LD && p.ldb <= TN_S3_MAX_LD && p.lda2 <= TN_S3_MAX_LD;
   TNPlan pl = tn_plan(p.P, p.Mo, p.Ni, PROB != PRO_GATE1 && ld_ok);
@@ -237,13 +284,29 @@ int launch_tn(TNParams p, float* slab, float* colsum_slab, float* C, long ldc, f
       if (pl.s3) {
         static const int attr_rc = allow_big_lds(gemm_tn_s3_kernel<PROA, PROB, 3>);
         static const int attr_rc1 = allow_big_lds(gemm_tn_s3_kernel<PROA, PROB, 1>);
+        static const int attr_rc2 = allow_big_lds(gemm_tn_s3_kernel<PROA, PROB, 2>);
         if (attr_rc != PRH_OK) return attr_rc;
         if (attr_rc1 != PRH_OK) return attr_rc1;
-        const bool one = gemm_mode() == 2;
-        snprintf(nm, sizeof(nm), "gemm_tn_%s<%d,%d> Mo=%d Ni=%d", one ? "b1" : "s3", PROA, PROB, p.Mo, p.Ni);
+        if (attr_rc2 != PRH_OK) return attr_rc2;
+        const int mode = gemm_mode();
+        if (mode == 3) {
+          float* hdr = slab + (size_t)pl.splits * p.Mo * p.Ni;
+          if (p.amaxA == nullptr) {
+            TRY_RC((measure_absmax<PROA>(p.A, p.lda, p.A2, p.lda2, p.pa, p.pb, p.pc, p.P, p.Mo, hdr, st)));
+            p.amaxA = hdr;
+          }
+          if (p.amaxB == nullptr) {
+            TRY_RC((measure_absmax<PROB>(p.B, p.ldb, nullptr, 0, p.qa, p.qb, nullptr, p.P, p.Ni, hdr + 1, st)));
+            p.amaxB = hdr + 1;
+          }
+        }
+        snprintf(nm, sizeof(nm), "gemm_tn_%s<%d,%d> Mo=%d Ni=%d", core_tag(), PROA, PROB, p.Mo, p.Ni);
         ProfScope ps(nm, 2.0 * p.P * (double)p.Mo * p.Ni, by, st);
-        if (one)
+        if (mode == 2)
           hipLaunchKernelGGL((gemm_tn_s3_kernel<PROA, PROB, 1>), dim3((unsigned)blocks), dim3(512),
+                             S3_LDS, st, p);
+        else if (mode == 3)
+          hipLaunchKernelGGL((gemm_tn_s3_kernel<PROA, PROB, 2>), dim3((unsigned)blocks), dim3(512),
                              S3_LDS, st, p);
         else
           hipLaunchKernelGGL((gemm_tn_s3_kernel<PROA, PROB, 3>), dim3((unsigned)blocks), dim3(512),
@@ -435,6 +498,7 @@ int stack_backward(const prh_bn_layer* ly, int L, const float* x, int P, int tra
                        gr ? gr[l].db : nullptr);
     LAUNCH_CHECK();
     // 2. wgrad: dW_l = dz_l^T h_{l-1}
+    const float* dz_amax = nullptr;     // largest |dz_l| when the wgrad launch measured it
     if (gr && gr[l].dw) {
       TNParams t; memset(&t, 0, sizeof(t));
       t.A = dy_cat + o; t.lda = lddy; t.A2 = z_cat + o; t.lda2 = ldz;
@@ -452,11 +516,13 @@ int stack_backward(const prh_bn_layer* ly, int L, const float* x, int P, int tra
         t.qa = scale + d.off[l - 1]; t.qb = shift + d.off[l - 1];
         TRY((launch_tn<PRO_BNBWD, PRO_BNRELU>(t, sc.slab, sc.colslab, gr[l].dw, (long)ly[l].cin, nullptr, st)));
       }
+      dz_amax = t.amaxA;
     }
     // 3. dgrad into the previous layer's block (accumulate + mask + its statistics)
     if (l > 0) {
       TRY(transpose(ly[l].w, co, ly[l].cin, sc.wT, st));     // wT [cin, cout]
       NTParams p; memset(&p, 0, sizeof(p));
+      p.amaxA = dz_amax;
       p.A = dy_cat + o; p.lda = lddy; p.A2 = z_cat + o; p.lda2 = ldz;
       p.pa = sc.ca; p.pb = sc.cb; p.pc = sc.cc;
       p.W = sc.wT; p.ldw = co; p.M = P; p.N = ly[l].cin; p.K = co;
@@ -549,7 +615,8 @@ extern "C" {
 
 const char* prh_last_error(void) { return g_err; }
 int prh_set_gemm_mode(int mode) {
-  if (mode < 0 || mode > 2) return fail(PRH_ERR_ARG, "gemm mode must be 0 (fp32), 1 (split-bf16) or 2 (bf16)");
+  if (mode < 0 || mode > 3)
+    return fail(PRH_ERR_ARG, "gemm mode must be 0 (fp32), 1 (split-bf16), 2 (bf16) or 3 (split-fp16)");
   g_gemm_mode = mode;
   return PRH_OK;
 }
@@ -814,16 +881,19 @@ int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B,
   // (2) fusion conv: wgrad over the virtual concat, dgrad into dy_cat (masked per layer),
   //     with layer-5 BN-backward partials (the only block that is complete here)
   StatInfo si5;
+  const float* dzf_amax = nullptr;
   if (gr->fusion.dw) {
     TNParams t; memset(&t, 0, sizeof(t));
     t.A = d_fused; t.lda = od; t.A2 = sv->z_fus; t.lda2 = od; t.pa = sc.ca; t.pb = sc.cb; t.pc = sc.cc;
     t.B = sv->z_cat; t.ldb = cat; t.qa = sv->bn_scale; t.qb = sv->bn_shift;
     t.P = P; t.Mo = od; t.Ni = cat;
     TRY((launch_tn<PRO_BNBWD, PRO_BNRELU>(t, fslab, fcslab, gr->fusion.dw, (long)cat, nullptr, st)));
+    dzf_amax = t.amaxA;
   }
   {
     TRY(transpose(prm->fusion.w, od, cat, sc.wT, st));   // [cat, od]
     NTParams p; memset(&p, 0, sizeof(p));
+    p.amaxA = dzf_amax;
     p.A = d_fused; p.lda = od; p.A2 = sv->z_fus; p.lda2 = od; p.pa = sc.ca; p.pb = sc.cb; p.pc = sc.cc;
     p.W = sc.wT; p.ldw = od; p.M = P; p.N = cat; p.K = od;
     p.C = dy_cat; p.ldc = cat; p.E1 = sv->z_cat; p.lde1 = cat; p.es = sv->bn_scale; p.et = sv->bn_shift;

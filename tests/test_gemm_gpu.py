@@ -13,9 +13,10 @@ def _p(t):
     return C.c_void_p(t.data_ptr())
 
 
-@pytest.fixture(scope="module", params=[0, 1], ids=["fp32", "split"])
+@pytest.fixture(scope="module", params=[0, 1, 3], ids=["fp32", "split", "split16"])
 def lib(request):
-    """Every case runs on the exact fp32 MFMA cores and on the split-bf16 cores."""
+    """Every case runs on the exact fp32 MFMA cores, the split-bf16 cores (3 planes, 6 products)
+    and the split-fp16 cores (2 scaled planes, 3 products)."""
     from pointnet_refine_amd import _lib
     l = _lib.lib()
     old = l.prh_get_gemm_mode()
@@ -86,14 +87,15 @@ def test_split_core_is_fp32_accurate():
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     errs = {}
     old = lib.prh_get_gemm_mode()
-    for mode in (0, 1):
+    for mode in (0, 1, 3):
         lib.prh_set_gemm_mode(mode)
         c = torch.empty(m, n, device="cuda")
         assert lib.prh_test_gemm_nt(_p(a), _p(w), _p(c), m, n, k, _p(ws), nb, 0, st) == 0
         errs[mode] = float((c.double() - ref).norm() / ref.norm())
     lib.prh_set_gemm_mode(old)
-    print("rel-L2 error vs fp64: fp32 core %.3e, split core %.3e" % (errs[0], errs[1]))
-    assert errs[0] < 1e-6 and errs[1] < 1e-6
+    print("rel-L2 error vs fp64: fp32 core %.3e, split-bf16 core %.3e, split-fp16 core %.3e"
+          % (errs[0], errs[1], errs[3]))
+    assert errs[0] < 1e-6 and errs[1] < 1e-6 and errs[3] < 1e-6
 
 
 def test_bf16_mode_is_reduced_precision_but_sane():
