@@ -318,11 +318,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // Two staging register sets: tile t lives in set t&1.  Iteration kt converts tile kt+1
-  // (loaded one iteration earlier, so its data has landed and the conversion VALU work has no
-  // wait in front of it and can be interleaved with the MFMAs of tile kt) and issues the
-  // loads of tile kt+2.
-  float4 ra[2][2], ra2[2][2];
+  // Three staging register sets: tile t lives in set t%3.  Iteration kt converts tile kt+1
+  // (loaded TWO iterations earlier: a k-tile of the three-product core is ~0.8 us of MFMA
+  // issue, less than an HBM round trip under load, so one k-tile of distance left the loads
+  // exposed - measured +25% on cache-resident A) and issues the loads of tile kt+3.
+  float4 ra[3][2], ra2[3][2];
   const char* wsrc = Wp + (size_t)tile_n * KT * S3_OPER + tid * 16;
   // wave-uniform LDS byte address of this wave's 1-KB slice of a W plane in stage 0
   const unsigned lds0 = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)smem);
@@ -331,7 +331,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
   // W planes: pre-split, pre-swizzled image -> straight global->LDS DMA (no registers, no
   // ds_write), issued from inline asm and waited for by the counted vmcnt that ends the k-tile.
   auto dma_w = [&](int kt, int stage) {
+#ifdef PRH_EXP_HOT_W
+    const char* q = wsrc + (size_t)(kt & 1) * S3_OPER;
+#else
     const char* q = wsrc + (size_t)(kt < KT ? kt : KT - 1) * S3_OPER;   // tail: harmless re-copy
+#endif
 #pragma unroll
     for (int pl = 0; pl < NPL; ++pl) glds16(q + pl * S3_PLANE, wdst + stage * S3_STAGE + pl * S3_PLANE);
   };
@@ -362,7 +366,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
     }
   }
   auto load_tile = [&](int kt, float4 (&r)[2], float4 (&r2)[2]) {
+#ifdef PRH_EXP_HOT_A
+    const int so = (kt & 1) * (S3_BK * 4);
+#else
     const int so = kt * (S3_BK * 4);
+#endif
     if (PRO == PRO_GATE1) return;     // operand is generated from gi[], nothing to load
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -400,9 +408,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
     }
   };
   // one k-tile: compute tile kt from its stage, convert tile kt+1 out of register set CS into
-  // the other stage, refill set CS^1 with tile kt+2.  Branch free (tail tiles load zeros).
+  // the other stage, refill set CS+2 (mod 3, the set tile kt was converted from) with tile
+  // kt+3.  Branch free (tail tiles load zeros).
   auto iter = [&](int kt, auto cs) {
     constexpr int CS = decltype(cs)::value;
+    constexpr int FS = (CS + 2) % 3;
     char* cur = smem + (kt & 1) * S3_STAGE;
     char* nxt = smem + ((kt + 1) & 1) * S3_STAGE;
     // First "use" of the registers converted in this k-tile, BEFORE any new memory operation is
@@ -420,7 +430,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
     }
     dma_w(kt + 1, (kt + 1) & 1);
     __builtin_amdgcn_sched_barrier(0);   // DMA strictly before the A loads (vmcnt is in order)
-    load_tile(kt + 2, ra[CS ^ 1], ra2[CS ^ 1]);
+    load_tile(kt + 3, ra[FS], ra2[FS]);
     // keep the memory operations at the head of the k-tile
     __builtin_amdgcn_sched_barrier(0);
     s3_compute<NPL>(acc, cur, wm, wn, l31, half);
@@ -454,6 +464,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
   __builtin_amdgcn_sched_barrier(0);
   load_tile(0, ra[0], ra2[0]);
   load_tile(1, ra[1], ra2[1]);
+  load_tile(2, ra[2], ra2[2]);
   if (PRO != PRO_NONE) {
     // per-k prologue coefficient vectors -> LDS once per block, zero beyond K (which also
     // zeroes the prologue output there: relu(a*0+0) = 0, 0*dy + 0*z + 0 = 0); two tiles of
@@ -470,11 +481,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // first W image landed (prologue only)
   __syncthreads();
   int kt = 0;
-  for (; kt + 1 < KT; kt += 2) {
+  for (; kt + 2 < KT; kt += 3) {
     iter(kt, std::integral_constant<int, 1>{});
-    iter(kt + 1, std::integral_constant<int, 0>{});
+    iter(kt + 1, std::integral_constant<int, 2>{});
+    iter(kt + 2, std::integral_constant<int, 0>{});
   }
   if (kt < KT) iter(kt, std::integral_constant<int, 1>{});
+  if (kt + 1 < KT) iter(kt + 1, std::integral_constant<int, 2>{});
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (NPL == 2) {

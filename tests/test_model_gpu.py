@@ -102,10 +102,14 @@ def test_full_size_properties():
         assert maxdiff(out[:, 37:41], out_sub) < 5e-5
         enc = m.context_encoder
         gf, fu = enc(ctx[:64].transpose(2, 1))
-        perm = torch.randperm(N, device="cuda")
+        perm = torch.randperm(N, generator=torch.Generator().manual_seed(7)).cuda()
         gf2, fu2 = enc(ctx[:64, perm].contiguous().transpose(2, 1))
         assert maxdiff(gf[:, :1024], gf2[:, :1024]) == 0.0           # max: exact
-        assert maxdiff(gf[:, 1024:], gf2[:, 1024:]) < 1e-5            # mean: summation order
+        # mean: fp32 running sums of N values in a different order differ by ~sqrt(N)*eps*|sum|
+        # (a few 1e-6 per unit of magnitude at N=1024); both must sit that close to the fp64 mean
+        mean64 = fu.double().mean(-1)
+        tol = 1e-5 * max(1.0, float(fu.max()))
+        assert maxdiff(gf[:, 1024:], mean64) < tol and maxdiff(gf2[:, 1024:], mean64) < tol
         assert maxdiff(fu[:, :, perm], fu2) < 1e-5
         assert float(fu.min()) >= 0.0
     # small oracle cross-check of a slice of the big batch (eval => batch independent)
