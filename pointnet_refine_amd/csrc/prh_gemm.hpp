@@ -22,6 +22,7 @@
 // are 16 B per lane along channels, 128 B contiguous per 8 lanes.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 namespace prh {
@@ -277,8 +278,19 @@ __device__ __forceinline__ void nt_epilogue_vec(f32x16 (&acc)[MT][2], const NTPa
   }
 
   const bool mask = (p.flags & F_MASK) != 0, accum = (p.flags & F_ACCUM) != 0;
-  const bool need_z = EPI == EPI_DGRAD && (mask || (p.flags & F_STATS) != 0);
+  const bool need_z = (EPI == EPI_DGRAD && (mask || (p.flags & F_STATS) != 0)) || EPI == EPI_GATE;
   float4 s1 = zero4(), s2 = zero4();
+  // The epilogue operands (z for the ReLU mask / statistics / gate, the old C when
+  // accumulating) are fetched in ONE batch per 32-row block, branch-free (rows and columns
+  // clamped into the tile's valid range; only the store is predicated), so a block exposes a
+  // single memory latency.  With the loads inside the per-row bounds and flag branches the
+  // compiler emitted load -> s_waitcnt vmcnt(0) -> load -> wait -> store for each of the 32
+  // row groups: ~100 serialized round trips per tile.
+  const int col4c = col4 < p.N ? col4 : (p.N - 4);
+  // load bases: a wave tile entirely below the matrix reads (and discards) row 0 instead
+  const float* __restrict__ Cl = mrows > 0 ? Cb : p.C;
+  const float* __restrict__ El = mrows > 0 ? Eb : p.E1;
+  const bool acc_old = EPI == EPI_DGRAD && accum;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     // accumulator block -> scratch (column layout: conflict-free 128-B rows)
@@ -286,44 +298,64 @@ __device__ __forceinline__ void nt_epilogue_vec(f32x16 (&acc)[MT][2], const NTPa
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) scratch[crow(r, half) * EPI_LDW + nt * 32 + l31] = acc[mt][nt][r];
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {     // two batches of 4 row groups (register budget)
+    // pin each batch's loads to its batch (the operand pointers are read-only/restrict, so the
+    // bases are laundered through an asm statement; hoisting the next batch spills accumulators)
+    const float* Em = El; const float* Cm = Cl;
+    asm volatile("" : "+s"(Em), "+s"(Cm) : : "memory");
+    float4 zz[4], oo[4];
+    int lrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      zz[i] = zero4(); oo[i] = zero4();
+      int r = mt * 32 + (hb * 4 + i) * 4 + rr;
+      r = r < mrows ? r : mrows - 1;
+      lrc[i] = r < 0 ? 0 : r;
+    }
+    if (need_z) {        // wave-uniform: one batch of loads
+#pragma unroll
+      for (int i = 0; i < 4; ++i) zz[i] = ldg4(Em + lrc[i] * lde1 + col4c);
+    }
+    if (acc_old) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) oo[i] = ldg4(Cm + lrc[i] * ldc + col4c);
+    }
     // scratch -> row-major float4 per lane
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
+    for (int i = 0; i < 4; ++i) {
+      const int it = hb * 4 + i;
       const int lrow = it * 4 + rr;
       const int lr = mt * 32 + lrow;
+      const bool ok = lr < mrows && c4ok;
       float4 v = *reinterpret_cast<const float4*>(scratch + lrow * EPI_LDW + c4);
-      if (lr < mrows && c4ok) {
-        v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
-        if (EPI == EPI_DGRAD) {
-          if (accum) {
-            const float4 o = ldg4(Cb + lr * ldc + col4);
-            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-          }
-          float4 z = zero4();
-          if (need_z) z = ldg4(Eb + lr * lde1 + col4);
-          if (mask) {
-            v.x = fmaf(z.x, es4.x, et4.x) > 0.f ? v.x : 0.f;
-            v.y = fmaf(z.y, es4.y, et4.y) > 0.f ? v.y : 0.f;
-            v.z = fmaf(z.z, es4.z, et4.z) > 0.f ? v.z : 0.f;
-            v.w = fmaf(z.w, es4.w, et4.w) > 0.f ? v.w : 0.f;
-          }
-          s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
-          s2.x = fmaf(v.x, z.x, s2.x); s2.y = fmaf(v.y, z.y, s2.y);
-          s2.z = fmaf(v.z, z.z, s2.z); s2.w = fmaf(v.w, z.w, s2.w);
-        } else if (EPI == EPI_GATE) {
-          // F = relu(zf*s+t) * m,  m = 0.5 + 0.5*sigmoid(acc + b)     (src/model.py:51,54-55)
-          const float4 zf = ldg4(Eb + lr * lde1 + col4);
-          float4 m;
-          m.x = 0.5f + 0.5f / (1.f + __expf(-v.x)); m.y = 0.5f + 0.5f / (1.f + __expf(-v.y));
-          m.z = 0.5f + 0.5f / (1.f + __expf(-v.z)); m.w = 0.5f + 0.5f / (1.f + __expf(-v.w));
-          v.x = fmaxf(fmaf(zf.x, es4.x, et4.x), 0.f) * m.x; v.y = fmaxf(fmaf(zf.y, es4.y, et4.y), 0.f) * m.y;
-          v.z = fmaxf(fmaf(zf.z, es4.z, et4.z), 0.f) * m.z; v.w = fmaxf(fmaf(zf.w, es4.w, et4.w), 0.f) * m.w;
-          if ((p.flags & F_STORE_GATE) != 0) *reinterpret_cast<float4*>(C2b + lr * ldc2 + col4) = m;
-        } else if ((p.flags & F_RELU_OUT) != 0) {
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+      const float4 z = zz[i];
+      if (EPI == EPI_DGRAD) {
+        v.x += oo[i].x; v.y += oo[i].y; v.z += oo[i].z; v.w += oo[i].w;
+        if (mask) {
+          v.x = fmaf(z.x, es4.x, et4.x) > 0.f ? v.x : 0.f;
+          v.y = fmaf(z.y, es4.y, et4.y) > 0.f ? v.y : 0.f;
+          v.z = fmaf(z.z, es4.z, et4.z) > 0.f ? v.z : 0.f;
+          v.w = fmaf(z.w, es4.w, et4.w) > 0.f ? v.w : 0.f;
         }
-        *reinterpret_cast<float4*>(Cb + lr * ldc + col4) = v;
+        const float4 q = ok ? v : zero4();
+        s1.x += q.x; s1.y += q.y; s1.z += q.z; s1.w += q.w;
+        s2.x = fmaf(q.x, z.x, s2.x); s2.y = fmaf(q.y, z.y, s2.y);
+        s2.z = fmaf(q.z, z.z, s2.z); s2.w = fmaf(q.w, z.w, s2.w);
+      } else if (EPI == EPI_GATE) {
+        // F = relu(zf*s+t) * m,  m = 0.5 + 0.5*sigmoid(acc + b)     (src/model.py:51,54-55)
+        float4 m;
+        m.x = 0.5f + 0.5f / (1.f + __expf(-v.x)); m.y = 0.5f + 0.5f / (1.f + __expf(-v.y));
+        m.z = 0.5f + 0.5f / (1.f + __expf(-v.z)); m.w = 0.5f + 0.5f / (1.f + __expf(-v.w));
+        v.x = fmaxf(fmaf(z.x, es4.x, et4.x), 0.f) * m.x; v.y = fmaxf(fmaf(z.y, es4.y, et4.y), 0.f) * m.y;
+        v.z = fmaxf(fmaf(z.z, es4.z, et4.z), 0.f) * m.z; v.w = fmaxf(fmaf(z.w, es4.w, et4.w), 0.f) * m.w;
+        if (ok && (p.flags & F_STORE_GATE) != 0) *reinterpret_cast<float4*>(C2b + lr * ldc2 + col4) = m;
+      } else if ((p.flags & F_RELU_OUT) != 0) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
       }
+      if (ok) *reinterpret_cast<float4*>(Cb + lr * ldc + col4) = v;
+    }
     }
   }
   if (EPI == EPI_DGRAD && (p.flags & F_STATS) != 0) {

@@ -79,6 +79,17 @@ __device__ __forceinline__ float pow2_scale(float amax) {
   return __uint_as_float((unsigned)se << 23);
 }
 
+// The operand maxima are written by the kernel launched just before (atomic max) at an address
+// that is reused launch after launch.  A plain load of a uniform, read-only address becomes a
+// scalar load, and the scalar cache may still hold the PREVIOUS launch's value (observed:
+// run-to-run differences at rounding level, i.e. a neighbouring power-of-two scale): read it
+// with an agent-scope atomic load, which is served by L2.
+__device__ __forceinline__ float load_amax(const float* p) {
+  const unsigned u = __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+  return __uint_as_float(__builtin_amdgcn_readfirstlane(u));
+}
+
 // split two (already scaled) floats into packed fp16 pairs (h, l)
 __device__ __forceinline__ void split2h(float a0, float a1, unsigned& h, unsigned& l) {
   f32x2 v = {a0, a1};
@@ -89,18 +100,21 @@ __device__ __forceinline__ void split2h(float a0, float a1, unsigned& h, unsigne
   l = *reinterpret_cast<unsigned*>(&lb);
 }
 
-// Largest magnitude of pro(A) over [rows, cols] -> atomic max on *out (float bits of a
-// non-negative value order like unsigned integers; *out is zeroed by the host).  One pass at
-// HBM rate: block = 64 column vectors x 4 rows, a thread keeps its column's prologue
-// coefficients in registers and walks down the rows (no per-element index arithmetic).
-// vec = 1: cols and the leading dimensions are multiples of 4 (16-B loads).
+// Largest magnitude of pro(A) over [rows, cols]: per-block maxima -> part[blockIdx.x], reduced
+// by absmax_final_kernel (plain kernels on the launch stream: no atomics, nothing to
+// pre-zero, so no memset whose ordering against queued kernels would have to be trusted).
+// One pass at HBM rate: block = 64 column vectors x 4 rows, a thread keeps its column's
+// prologue coefficients in registers and walks down the rows (no per-element index
+// arithmetic).  vec = 1: cols and the leading dimensions are multiples of 4 (16-B loads).
+constexpr int ABSMAX_MAX_BLOCKS = 2048;
 template <int PRO>
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ A, long lda,
                                                      const float* __restrict__ A2, long lda2,
                                                      const float* __restrict__ pa,
                                                      const float* __restrict__ pb,
                                                      const float* __restrict__ pc, long rows,
-                                                     int cols, int vec, unsigned* __restrict__ out) {
+                                                     int cols, int vec, float* __restrict__ part) {
+  __shared__ float red[4];
   float m = 0.f;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const long r0 = (long)blockIdx.x * 4 + ty, rstep = (long)gridDim.x * 4;
@@ -134,7 +148,21 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ A
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if (tx == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+  if (tx == 0) red[ty] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+__global__ __launch_bounds__(256) void absmax_final_kernel(const float* __restrict__ part, int n,
+                                                           float* __restrict__ out) {
+  __shared__ float red[4];
+  float m = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, part[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -167,7 +195,7 @@ __global__ __launch_bounds__(256) void prep_weights_s3_kernel(const float* __res
   uint4 h, m, l;
   char* base = out + ((size_t)n_tile * KT + k_tile) * S3_OPER + s3_off(row, chunk * 8);
   if (amax != nullptr) {
-    const float S = pow2_scale(*amax);
+    const float S = pow2_scale(load_amax(amax));
     split2h(v[0] * S, v[1] * S, h.x, l.x);
     split2h(v[2] * S, v[3] * S, h.y, l.y);
     split2h(v[4] * S, v[5] * S, h.z, l.z);
@@ -185,7 +213,9 @@ __global__ __launch_bounds__(256) void prep_weights_s3_kernel(const float* __res
   *reinterpret_cast<uint4*>(base + 2 * S3_PLANE) = l;
 }
 
-constexpr int S3_WHDR = 256;   // head of a weight image: [0] largest |W|, [1] largest |pro(A)| (floats)
+// head of a weight image (floats): [0] largest |W|, [1] largest |pro(A)|, [64..) per-block maxima
+constexpr int S3_HDR_FLOATS = 64 + ABSMAX_MAX_BLOCKS;
+constexpr int S3_WHDR = ((S3_HDR_FLOATS * 4 + 255) / 256) * 256;
 inline size_t s3_weight_bytes(int N, int K) {
   return S3_WHDR + (size_t)((N + S3_BN - 1) / S3_BN) * ((K + S3_BK - 1) / S3_BK) * S3_OPER;
 }
@@ -306,8 +336,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
   // fp16 planes: operand scales (powers of two), folded into the prologue coefficients
   float sA = 1.f, unscale = 1.f;
   if (NPL == 2) {
-    sA = pow2_scale(*p.amaxA);
-    unscale = 1.f / (sA * pow2_scale(*p.amaxW));
+    sA = pow2_scale(load_amax(p.amaxA));
+    unscale = 1.f / (sA * pow2_scale(load_amax(p.amaxW)));
   }
 
   f32x16 acc[4][2];
@@ -549,8 +579,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_s3_kernel(const TNParams p) {
   // fp16 planes: operand scales (powers of two) folded into the per-column coefficients
   float sA = 1.f, sB = 1.f;
   if (NPL == 2) {
-    sA = pow2_scale(*p.amaxA);
-    sB = pow2_scale(*p.amaxB);
+    sA = pow2_scale(load_amax(p.amaxA));
+    sB = pow2_scale(load_amax(p.amaxB));
     ka *= sA; kb *= sA; kc *= sA; qa *= sB; qb *= sB;
   }
 

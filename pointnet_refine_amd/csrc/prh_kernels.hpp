@@ -80,7 +80,9 @@ __global__ void bn_fwd_finalize_kernel(const double* __restrict__ sl, int P, int
                                        float* mean_out, float* rstd_out, float* scale_out,
                                        float* shift_out) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (nbt != nullptr && col == 0) *nbt += 1;
+  // atomic: a plain uniform read-modify-write is a scalar load, which may be served from a
+  // scalar-cache line that predates the previous launch's increment
+  if (nbt != nullptr && col == 0) atomicAdd(reinterpret_cast<unsigned long long*>(nbt), 1ull);
   if (col >= N) return;
   double n = 0.0, mean = 0.0, m2 = 0.0;
   for (int s = 0; s < BN_SLICES; ++s) {

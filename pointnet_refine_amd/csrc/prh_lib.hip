@@ -117,19 +117,24 @@ inline int gemm_mode() {
 }
 inline const char* core_tag() { return gemm_mode() == 2 ? "b1" : (gemm_mode() == 3 ? "h2" : "s3"); }
 
-// largest |pro(A)| over [rows, cols] into *slot (zeroed here)
+// largest |pro(A)| over [rows, cols] into *slot; part: ABSMAX_MAX_BLOCKS floats of scratch
 template <int PRO>
 int measure_absmax(const float* A, long lda, const float* A2, long lda2, const float* pa,
-                   const float* pb, const float* pc, long rows, int cols, float* slot,
+                   const float* pb, const float* pc, long rows, int cols, float* slot, float* part,
                    hipStream_t st) {
-  HIP_TRY(hipMemsetAsync(slot, 0, sizeof(float), st));
-  if (rows <= 0 || cols <= 0) return PRH_OK;
+  if (rows <= 0 || cols <= 0) {
+    hipLaunchKernelGGL(absmax_final_kernel, dim3(1), dim3(256), 0, st, part, 0, slot);
+    LAUNCH_CHECK();
+    return PRH_OK;
+  }
   const int vec = ((cols & 3) == 0 && (PRO == PRO_GATE1 || (lda & 3) == 0) &&
                    (PRO != PRO_BNBWD || (lda2 & 3) == 0)) ? 1 : 0;
   long blocks = cdiv(rows, 4L * 8);      // >= 8 rows per thread column, at most 8 blocks per CU
-  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  blocks = blocks < 1 ? 1 : (blocks > ABSMAX_MAX_BLOCKS ? ABSMAX_MAX_BLOCKS : blocks);
   hipLaunchKernelGGL((absmax_kernel<PRO>), dim3((unsigned)blocks), dim3(256), 0, st, A, lda, A2, lda2,
-                     pa, pb, pc, rows, cols, vec, reinterpret_cast<unsigned*>(slot));
+                     pa, pb, pc, rows, cols, vec, part);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(absmax_final_kernel, dim3(1), dim3(256), 0, st, part, (int)blocks, slot);
   LAUNCH_CHECK();
   return PRH_OK;
 }
@@ -181,10 +186,10 @@ int launch_nt(NTParams p, hipStream_t st, StatInfo* si = nullptr) {
       float* hdr = reinterpret_cast<float*>(p.wprep);
       const char* img = p.wprep + S3_WHDR;
       if (mode == 3) {      // operand scales of the fp16-plane core
-        TRY_RC((measure_absmax<PRO_NONE>(p.W, p.ldw, nullptr, 0, nullptr, nullptr, nullptr, p.N, p.K, hdr, st)));
+        TRY_RC((measure_absmax<PRO_NONE>(p.W, p.ldw, nullptr, 0, nullptr, nullptr, nullptr, p.N, p.K, hdr, hdr + 64, st)));
         p.amaxW = hdr;
         if (p.amaxA == nullptr) {
-          TRY_RC((measure_absmax<PRO>(p.A, p.lda, p.A2, p.lda2, p.pa, p.pb, p.pc, p.M, p.K, hdr + 1, st)));
+          TRY_RC((measure_absmax<PRO>(p.A, p.lda, p.A2, p.lda2, p.pa, p.pb, p.pc, p.M, p.K, hdr + 1, hdr + 64, st)));
           p.amaxA = hdr + 1;
         }
       }
@@ -250,7 +255,8 @@ inline TNPlan tn_plan(int P, int Mo, int Ni, bool allow_s3) {
   pl.rows_per_split = rps;
   return pl;
 }
-constexpr int TN_HDR = 64;   // floats behind a slab: [0] largest |proA(A)|, [1] largest |proB(B)|
+// floats behind a slab: [0] largest |proA(A)|, [1] largest |proB(B)|, [64..) per-block maxima
+constexpr int TN_HDR = S3_HDR_FLOATS;
 inline size_t tn_slab_floats(int P, int Mo, int Ni) {   // upper bound over both cores
   const size_t a = (size_t)tn_plan(P, Mo, Ni, true).splits, b = (size_t)tn_plan(P, Mo, Ni, false).splits;
   return (a > b ? a : b) * Mo * Ni + TN_HDR;
@@ -292,11 +298,11 @@ int launch_tn(TNParams& p, float* slab, float* colsum_slab, float* C, long ldc, 
         if (mode == 3) {
           float* hdr = slab + (size_t)pl.splits * p.Mo * p.Ni;
           if (p.amaxA == nullptr) {
-            TRY_RC((measure_absmax<PROA>(p.A, p.lda, p.A2, p.lda2, p.pa, p.pb, p.pc, p.P, p.Mo, hdr, st)));
+            TRY_RC((measure_absmax<PROA>(p.A, p.lda, p.A2, p.lda2, p.pa, p.pb, p.pc, p.P, p.Mo, hdr, hdr + 64, st)));
             p.amaxA = hdr;
           }
           if (p.amaxB == nullptr) {
-            TRY_RC((measure_absmax<PROB>(p.B, p.ldb, nullptr, 0, p.qa, p.qb, nullptr, p.P, p.Ni, hdr + 1, st)));
+            TRY_RC((measure_absmax<PROB>(p.B, p.ldb, nullptr, 0, p.qa, p.qb, nullptr, p.P, p.Ni, hdr + 1, hdr + 64, st)));
             p.amaxB = hdr + 1;
           }
         }

@@ -1,9 +1,9 @@
 #!/bin/bash
-# GEMM/encoder parity in split16 mode, then per-launch durations of the encoder
+# GEMM/encoder/model parity in split16 mode, then per-launch durations of the encoder
 set -o pipefail
 mkdir -p gpurun_out
-PRH_GEMM=split16 timeout -k 10 600 python -m pytest tests/test_gemm_gpu.py tests/test_encoder_gpu.py tests/test_model_gpu.py -q -m gpu -x 2>&1 | tail -5 > gpurun_out/h2_tests.log || { cat gpurun_out/h2_tests.log; exit 1; }
-cat gpurun_out/h2_tests.log
+PRH_GEMM=split16 timeout -k 10 600 python -m pytest tests/test_gemm_gpu.py tests/test_encoder_gpu.py tests/test_model_gpu.py -q -m gpu -x > gpurun_out/h2_tests.log 2>&1 || { grep -v "^$" gpurun_out/h2_tests.log | tail -60; exit 1; }
+tail -3 gpurun_out/h2_tests.log
 PRH_GEMM=split16 timeout -k 10 200 python scripts/encoder_bench.py ${1:-1024} 1024 3 > gpurun_out/enc_split16.log 2>&1 || { tail -20 gpurun_out/enc_split16.log; exit 1; }
 if grep -qi fault gpurun_out/enc_split16.log; then echo FAULT; exit 1; fi
 cat gpurun_out/enc_split16.log
