@@ -32,6 +32,8 @@ sys.path.insert(0, ROOT)
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # dense v_mfma_f32_32x32x16_bf16
 SPLIT_PRODUCTS = 6                 # bf16 MFMA products per fp32-accurate MAC on the split cores
+SPLIT16_PRODUCTS = 3               # fp16 MFMA products per fp32-accurate MAC on the split-fp16 cores
+DEFAULT_GEMM = "split"
 HBM_PEAK_GBS = 8000.0
 
 
@@ -66,9 +68,11 @@ def parse():
     ap.add_argument("--decoder-chunk", type=int, default=2048,
                     help="segments per decoder micro-batch (bounds the stock-PyTorch decoder's "
                          "activation memory; results are identical to the unchunked step)")
-    ap.add_argument("--gemm", choices=["split", "fp32", "bf16"], default="split",
-                    help="GEMM cores: split = 3xbf16-split MFMA with fp32-level error (default, the "
-                         "parity path); fp32 = exact fp32 MFMA; bf16 = reduced precision (config 3)")
+    ap.add_argument("--gemm", choices=["split16", "split", "fp32", "bf16"], default=DEFAULT_GEMM,
+                    help="GEMM cores for the large GEMMs. split16 = two scaled fp16 planes, 3 MFMA "
+                         "products, fp32-level error; split = three bf16 planes, 6 products, fp32-level "
+                         "error, no range assumption; fp32 = exact fp32 MFMA everywhere; bf16 = reduced "
+                         "precision (config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16)
     return ap.parse_args()
@@ -136,7 +140,7 @@ def main():
     from pointnet_refine_amd.synth import synthetic_batch
     from pointnet_refine_amd.train_step import TrainStep
     lib = _lib.lib()
-    lib.prh_set_gemm_mode({"fp32": 0, "split": 1, "bf16": 2}[args.gemm])
+    lib.prh_set_gemm_mode({"fp32": 0, "split": 1, "bf16": 2, "split16": 3}[args.gemm])
 
     torch.manual_seed(0)
     model = LineRefineNet().to(dev).train()
@@ -193,13 +197,17 @@ def main():
     # MFMA products per fp32-accurate MAC - the dense bf16 MFMA peak divided by 6.
     split = "_s3" in dname
     one = "_b1" in dname
-    peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS if split else (BF16_MFMA_PEAK_TFLOPS if one else FP32_MFMA_PEAK_TFLOPS)
+    h2 = "_h2" in dname
+    products = SPLIT_PRODUCTS if split else (SPLIT16_PRODUCTS if h2 else 1)
+    peak = BF16_MFMA_PEAK_TFLOPS / products if (split or h2 or one) else FP32_MFMA_PEAK_TFLOPS
     roofline = {"bound": "mfma", "kernel": dname, "achieved": round(achieved, 2),
                 "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "peak_basis": ("2500 TF dense bf16 MFMA / 6 products per fp32-accurate MAC (3-plane bf16 split)"
-                               if split else ("2500 TF dense bf16 MFMA" if one else
-                                              "157.3 TF fp32 MFMA (v_mfma_f32_32x32x2_f32)")),
-                "issued_mfma_tflops": round(achieved * (SPLIT_PRODUCTS if split else 1), 1),
+                               if split else ("2500 TF dense fp16 MFMA / 3 products per fp32-accurate MAC "
+                                              "(2 scaled fp16 planes)" if h2 else
+                                              ("2500 TF dense bf16 MFMA" if one else
+                                               "157.3 TF fp32 MFMA (v_mfma_f32_32x32x2_f32)"))),
+                "issued_mfma_tflops": round(achieved * products, 1),
                 "vs_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                 "traffic": pmc_traffic(dname, B, N, lib.prh_get_gemm_mode()),
                 "traffic_source": "profiles/r01_pmc_traffic_B4096.json (rocprofv3 --pmc FETCH_SIZE x2, WRITE_SIZE)",
@@ -217,7 +225,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": {0: "f32", 1: "f32 (large GEMMs: 3xbf16-split MFMA, fp32 accumulate)",
-                      2: "bf16 MFMA operands, fp32 accumulate and storage (reduced precision)"}[lib.prh_get_gemm_mode()],
+                      2: "bf16 MFMA operands, fp32 accumulate and storage (reduced precision)",
+                      3: "f32 (large GEMMs: 2xfp16-split MFMA, 3 products, fp32 accumulate)"}[lib.prh_get_gemm_mode()],
             "data": "synthetic",
             "config": {"workload": f"LineRefineNet training step (fwd + deep-supervision L1 + bwd + Adam), "
                                    f"B={B}/GPU, N={N}, M=32, C=4, fp32",

@@ -153,11 +153,50 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ A
   if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
+// BatchNorm backward applied in place:  dy <- ka*dy + kb*z + kc  (= dz), with the per-block
+// maxima of |dz| for the operand scale.  The split-fp16 wgrad and dgrad of a layer then both
+// read dz as a plain operand (4 B/element each instead of dy and z, 8 B, twice), and the
+// largest magnitude is exact and free.  Same walk as absmax_kernel (vec = 1 only: cols, ld % 4).
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ dy, long lddy,
+                                                           const float* __restrict__ z, long ldz,
+                                                           const float* __restrict__ pa,
+                                                           const float* __restrict__ pb,
+                                                           const float* __restrict__ pc, long rows,
+                                                           int cols, float* __restrict__ part) {
+  __shared__ float red[4];
+  float m = 0.f;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long r0 = (long)blockIdx.x * 4 + ty, rstep = (long)gridDim.x * 4;
+  const int c4 = cols >> 2;
+  for (int cv = tx; cv < c4; cv += 64) {
+    const int c = cv * 4;
+    const float4 ka = ldg4(pa + c), kb = ldg4(pb + c), kc = ldg4(pc + c);
+#pragma unroll 4
+    for (long r = r0; r < rows; r += rstep) {
+      float* q = dy + r * lddy + c;
+      const float4 v = pro_apply<PRO_BNBWD>(ldg4(q), ldg4(z + r * ldz + c), ka, kb, kc);
+      *reinterpret_cast<float4*>(q) = v;
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if (tx == 0) red[ty] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
 __global__ __launch_bounds__(256) void absmax_final_kernel(const float* __restrict__ part, int n,
                                                            float* __restrict__ out) {
   __shared__ float red[4];
   float m = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, part[i]);
+  // part[] is rewritten by every measurement and this one-block kernel tends to land on the CU
+  // that reduced the previous one: read through to L2 (agent-scope loads) rather than trust
+  // that the vector L1 holds no line of the previous contents (observed: stale maxima, i.e. the
+  // scale of the previously measured operand, with overflow to inf in the fp16 planes)
+  for (int i = threadIdx.x; i < n; i += 256)
+    m = fmaxf(m, __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(part) + i,
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
@@ -440,9 +479,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
   // one k-tile: compute tile kt from its stage, convert tile kt+1 out of register set CS into
   // the other stage, refill set CS+2 (mod 3, the set tile kt was converted from) with tile
   // kt+3.  Branch free (tail tiles load zeros).
-  auto iter = [&](int kt, auto cs) {
+  // TAIL (the peeled iterations behind the unrolled loop): no prefetch is issued - its data
+  // would never be used, and the compiler deletes such loads anyway, which silently breaks a
+  // counted wait that assumes them (seen: the W image of the last k-tile read before it
+  // landed, on layers with KT % 3 == 2, when the DMA was slower than the k-tile) - and the
+  // k-tile ends on vmcnt(0).
+  auto iter = [&](int kt, auto cs, auto tail) {
     constexpr int CS = decltype(cs)::value;
     constexpr int FS = (CS + 2) % 3;
+    constexpr bool TAIL = decltype(tail)::value;
     char* cur = smem + (kt & 1) * S3_STAGE;
     char* nxt = smem + ((kt + 1) & 1) * S3_STAGE;
     // First "use" of the registers converted in this k-tile, BEFORE any new memory operation is
@@ -460,7 +505,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
     }
     dma_w(kt + 1, (kt + 1) & 1);
     __builtin_amdgcn_sched_barrier(0);   // DMA strictly before the A loads (vmcnt is in order)
-    load_tile(kt + 3, ra[FS], ra2[FS]);
+    if (!TAIL) load_tile(kt + 3, ra[FS], ra2[FS]);
     // keep the memory operations at the head of the k-tile
     __builtin_amdgcn_sched_barrier(0);
     s3_compute<NPL>(acc, cur, wm, wn, l31, half);
@@ -486,7 +531,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
       }
     }
     // the DMA of this k-tile (older than its NA register loads) must have landed
-    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NA) : "memory");
+    if (TAIL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NA) : "memory");
     __syncthreads();
   };
 
@@ -512,12 +558,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
   __syncthreads();
   int kt = 0;
   for (; kt + 2 < KT; kt += 3) {
-    iter(kt, std::integral_constant<int, 1>{});
-    iter(kt + 1, std::integral_constant<int, 2>{});
-    iter(kt + 2, std::integral_constant<int, 0>{});
+    iter(kt, std::integral_constant<int, 1>{}, std::false_type{});
+    iter(kt + 1, std::integral_constant<int, 2>{}, std::false_type{});
+    iter(kt + 2, std::integral_constant<int, 0>{}, std::false_type{});
   }
-  if (kt < KT) iter(kt, std::integral_constant<int, 1>{});
-  if (kt + 1 < KT) iter(kt + 1, std::integral_constant<int, 2>{});
+  if (kt < KT) iter(kt, std::integral_constant<int, 1>{}, std::true_type{});
+  if (kt + 1 < KT) iter(kt + 1, std::integral_constant<int, 2>{}, std::true_type{});
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (NPL == 2) {

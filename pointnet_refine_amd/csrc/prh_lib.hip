@@ -147,6 +147,23 @@ inline bool nt_use_s3(int M, int N, int K) {
 }
 inline bool tn_use_s3(int P, int Mo, int Ni) { return split_enabled() && Mo >= 128 && Ni >= 64 && P >= 8192; }
 
+// dy <- dz in place (split-fp16 mode), largest |dz| into hdr[0]; hdr: S3_HDR_FLOATS floats
+int materialize_dz(float* dy, long lddy, const float* z, long ldz, const float* ka, const float* kb,
+                   const float* kc, long rows, int cols, float* hdr, hipStream_t st) {
+  long blocks = cdiv(rows, 4L * 8);
+  blocks = blocks < 1 ? 1 : (blocks > ABSMAX_MAX_BLOCKS ? ABSMAX_MAX_BLOCKS : blocks);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dy, lddy, z, ldz, ka,
+                     kb, kc, rows, cols, hdr + 64);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(absmax_final_kernel, dim3(1), dim3(256), 0, st, hdr + 64, (int)blocks, hdr);
+  LAUNCH_CHECK();
+  return PRH_OK;
+}
+// dz is materialised when the layer is aligned for 16-B accesses and the split-fp16 cores are on
+inline bool dz_in_place(int cols, long lddy, long ldz) {
+  return gemm_mode() == 3 && (cols & 3) == 0 && (lddy & 3) == 0 && (ldz & 3) == 0;
+}
+
 // Statistics partials: `count` tiles of `rows` rows each
 struct StatInfo { int count = 0; int rows = 64; long ld = 0; long off = 0; };   // ld 0: = layer width
 inline int stat_tiles_max(int P) { return 2 * cdiv(P, BM); }   // largest count any producer writes
@@ -481,7 +498,7 @@ int stack_forward(const prh_bn_layer* ly, int L, const float* x, int P, int trai
 //   complete masked gradient for l = L-1.  stats_ready: BN-backward partials of layer L-1
 //   are already in w.ws_a/ws_b.
 // Scratch: coef [3*maxc], wT [max cin*cout], slab, colslab.
-struct StackBwdScratch { float* ca; float* cb; float* cc; float* wT; float* slab; float* colslab; float* dxpad; };
+struct StackBwdScratch { float* ca; float* cb; float* cc; float* wT; float* slab; float* colslab; float* dxpad; float* hdr; };
 
 int stack_backward(const prh_bn_layer* ly, int L, const float* x, int P, int training,
                    float* dy_cat, long lddy, const float* z_cat, long ldz, const float* scale,
@@ -503,24 +520,31 @@ int stack_backward(const prh_bn_layer* ly, int L, const float* x, int P, int tra
                        sc.ca, sc.cb, sc.cc, gr ? gr[l].dgamma : nullptr, gr ? gr[l].dbeta : nullptr,
                        gr ? gr[l].db : nullptr);
     LAUNCH_CHECK();
+    // 1b. split-fp16 mode: dy_l <- dz_l in place, so wgrad and dgrad read one plain operand
+    const bool mat = dz_in_place(co, lddy, ldz);
+    const float* dz_amax = nullptr;     // largest |dz_l| once known
+    if (mat) {
+      TRY(materialize_dz(dy_cat + o, lddy, z_cat + o, ldz, sc.ca, sc.cb, sc.cc, P, co, sc.hdr, st));
+      dz_amax = sc.hdr;
+    }
     // 2. wgrad: dW_l = dz_l^T h_{l-1}
-    const float* dz_amax = nullptr;     // largest |dz_l| when the wgrad launch measured it
     if (gr && gr[l].dw) {
       TNParams t; memset(&t, 0, sizeof(t));
       t.A = dy_cat + o; t.lda = lddy; t.A2 = z_cat + o; t.lda2 = ldz;
       t.P = P; t.Mo = co; t.pa = sc.ca; t.pb = sc.cb; t.pc = sc.cc;
+      t.amaxA = dz_amax;
       if (l == 0) {
         t.B = x0; t.ldb = ldx; t.Ni = k0;
-        if (k0 == d.cin0) {
-          TRY((launch_tn<PRO_BNBWD, PRO_NONE>(t, sc.slab, sc.colslab, gr[l].dw, (long)k0, nullptr, st)));
-        } else {   // padded input: reduce into scratch, then drop the pad columns
-          TRY((launch_tn<PRO_BNBWD, PRO_NONE>(t, sc.slab, sc.colslab, sc.wT, (long)k0, nullptr, st)));
+        float* out = k0 == d.cin0 ? gr[l].dw : sc.wT;   // padded input: reduce into scratch ...
+        if (mat) TRY((launch_tn<PRO_NONE, PRO_NONE>(t, sc.slab, sc.colslab, out, (long)k0, nullptr, st)));
+        else TRY((launch_tn<PRO_BNBWD, PRO_NONE>(t, sc.slab, sc.colslab, out, (long)k0, nullptr, st)));
+        if (k0 != d.cin0)                                // ... then drop the pad columns
           TRY(copy_cols(sc.wT, k0, d.cin0, gr[l].dw, d.cin0, d.cin0, (size_t)co, st));
-        }
       } else {
         t.B = z_cat + d.off[l - 1]; t.ldb = ldz; t.Ni = ly[l].cin;
         t.qa = scale + d.off[l - 1]; t.qb = shift + d.off[l - 1];
-        TRY((launch_tn<PRO_BNBWD, PRO_BNRELU>(t, sc.slab, sc.colslab, gr[l].dw, (long)ly[l].cin, nullptr, st)));
+        if (mat) TRY((launch_tn<PRO_NONE, PRO_BNRELU>(t, sc.slab, sc.colslab, gr[l].dw, (long)ly[l].cin, nullptr, st)));
+        else TRY((launch_tn<PRO_BNBWD, PRO_BNRELU>(t, sc.slab, sc.colslab, gr[l].dw, (long)ly[l].cin, nullptr, st)));
       }
       dz_amax = t.amaxA;
     }
@@ -537,7 +561,8 @@ int stack_backward(const prh_bn_layer* ly, int L, const float* x, int P, int tra
       p.es = scale + d.off[l - 1]; p.et = shift + d.off[l - 1];
       p.ws_a = w.ws_a; p.ws_b = w.ws_b; p.wprep = w.wprep;
       p.flags = F_ACCUM | F_MASK | F_STATS;
-      TRY((launch_nt<PRO_BNBWD, EPI_DGRAD>(p, st, &si)));
+      if (mat) TRY((launch_nt<PRO_NONE, EPI_DGRAD>(p, st, &si)));
+      else TRY((launch_nt<PRO_BNBWD, EPI_DGRAD>(p, st, &si)));
       si.ld = 0; si.off = 0;
     } else if (dx != nullptr) {
       // dx = dz_0 W_0  (W_0^T is [cin0p, cout] with zero pad rows)
@@ -550,7 +575,9 @@ int stack_backward(const prh_bn_layer* ly, int L, const float* x, int P, int tra
       p.W = sc.wT; p.ldw = co; p.M = P; p.N = d.cin0; p.K = co;
       p.C = dx; p.ldc = d.cin0;
       p.flags = 0;
-      TRY((launch_nt<PRO_BNBWD, EPI_DGRAD>(p, st)));
+      p.amaxA = dz_amax;
+      if (mat) TRY((launch_nt<PRO_NONE, EPI_DGRAD>(p, st)));
+      else TRY((launch_nt<PRO_BNBWD, EPI_DGRAD>(p, st)));
     }
   }
   return PRH_OK;
@@ -574,6 +601,7 @@ void stack_bwd_scratch_carve(Arena& a, StackBwdScratch& sc, int P, const prh_bn_
   int mc = max_cout(ly, L); if (extra_c > mc) mc = extra_c;
   size_t mw = max_w(ly, L); if (extra_w > mw) mw = extra_w;
   sc.ca = a.f(mc); sc.cb = a.f(mc); sc.cc = a.f(mc);
+  sc.hdr = a.f(S3_HDR_FLOATS);
   sc.wT = a.f(mw);
   size_t slab = 0, cs = 0;
   for (int l = 0; l < L; ++l) {
@@ -888,12 +916,19 @@ int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B,
   //     with layer-5 BN-backward partials (the only block that is complete here)
   StatInfo si5;
   const float* dzf_amax = nullptr;
+  const bool matf = dz_in_place(od, (long)od, (long)od);
+  if (matf) {       // split-fp16 mode: d_fused <- dz_f in place (it is scratch from here on)
+    TRY(materialize_dz(d_fused, (long)od, sv->z_fus, (long)od, sc.ca, sc.cb, sc.cc, P, od, sc.hdr, st));
+    dzf_amax = sc.hdr;
+  }
   if (gr->fusion.dw) {
     TNParams t; memset(&t, 0, sizeof(t));
     t.A = d_fused; t.lda = od; t.A2 = sv->z_fus; t.lda2 = od; t.pa = sc.ca; t.pb = sc.cb; t.pc = sc.cc;
     t.B = sv->z_cat; t.ldb = cat; t.qa = sv->bn_scale; t.qb = sv->bn_shift;
     t.P = P; t.Mo = od; t.Ni = cat;
-    TRY((launch_tn<PRO_BNBWD, PRO_BNRELU>(t, fslab, fcslab, gr->fusion.dw, (long)cat, nullptr, st)));
+    t.amaxA = dzf_amax;
+    if (matf) TRY((launch_tn<PRO_NONE, PRO_BNRELU>(t, fslab, fcslab, gr->fusion.dw, (long)cat, nullptr, st)));
+    else TRY((launch_tn<PRO_BNBWD, PRO_BNRELU>(t, fslab, fcslab, gr->fusion.dw, (long)cat, nullptr, st)));
     dzf_amax = t.amaxA;
   }
   {
@@ -909,7 +944,8 @@ int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B,
     // layers 1..4 are recomputed by the dgrad that completes them
     p.ws_a = w.ws_a; p.ws_b = w.ws_b;
     p.flags = F_MASK | F_STATS;
-    TRY((launch_nt<PRO_BNBWD, EPI_DGRAD>(p, st, &si5)));
+    if (matf) TRY((launch_nt<PRO_NONE, EPI_DGRAD>(p, st, &si5)));
+    else TRY((launch_nt<PRO_BNBWD, EPI_DGRAD>(p, st, &si5)));
     si5.ld = cat; si5.off = d.off[4];
   }
   // (3) conv5..conv1
