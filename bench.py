@@ -33,7 +33,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # dense v_mfma_f32_32x32x16_bf16
 SPLIT_PRODUCTS = 6                 # bf16 MFMA products per fp32-accurate MAC on the split cores
 SPLIT16_PRODUCTS = 3               # fp16 MFMA products per fp32-accurate MAC on the split-fp16 cores
-DEFAULT_GEMM = "split"
+DEFAULT_GEMM = "split16"
 HBM_PEAK_GBS = 8000.0
 
 

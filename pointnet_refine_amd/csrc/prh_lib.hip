@@ -48,7 +48,7 @@ int fail(int code, const char* fmt, ...) {
     if (rc_ != PRH_OK) return rc_; \
   } while (0)
 #ifndef PRH_GEMM_DEFAULT
-#define PRH_GEMM_DEFAULT 1
+#define PRH_GEMM_DEFAULT 3
 #endif
 
 // ------------------------------------------------------------------ optional profiler
@@ -98,8 +98,9 @@ struct Arena {
 };
 
 // Which GEMM core serves a launch.  PRH_GEMM=fp32 forces the exact fp32 MFMA cores
-// everywhere; default "split" routes large GEMMs to the 3-plane bf16 cores (fp32-level
-// error, 2.67x higher matrix ceiling) and keeps small / odd-shaped ones on the fp32 cores.
+// everywhere; the default "split16" routes large GEMMs to the two-plane fp16 cores (fp32-level
+// error, 3 MFMA products per MAC: 5.3x the fp32 matrix ceiling), "split" to the three-plane
+// bf16 cores (6 products, no range assumption); small / odd-shaped GEMMs stay on the fp32 cores.
 // -1: not initialised, 0: fp32 cores only, 1: split-bf16 (3 planes, 6 products, fp32-accurate)
 // for large GEMMs, 2: plain bf16 operands (1 plane) for large GEMMs - reduced precision,
 // opt-in only, 3: split-fp16 (2 scaled planes, 3 products, fp32-accurate) for large GEMMs
@@ -655,7 +656,7 @@ int prh_set_gemm_mode(int mode) {
   return PRH_OK;
 }
 int prh_get_gemm_mode(void) { return gemm_mode(); }
-const char* prh_version(void) { return "pointnet_refine_hip 0.2 (gfx950: fp32 MFMA 32x32x2 + split-bf16 MFMA 32x32x16 cores)"; }
+const char* prh_version(void) { return "pointnet_refine_hip 0.3 (gfx950: fp32 MFMA 32x32x2 + split-fp16 / split-bf16 MFMA 32x32x16 cores)"; }
 
 // ------------------------------------------------------------------ Linear
 size_t prh_linear_forward_workspace_bytes(int rows, int k, int n) {

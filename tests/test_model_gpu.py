@@ -118,9 +118,10 @@ def test_full_size_properties():
     assert maxdiff(out[:, 100:102], o) < 1e-4
 
 
-@pytest.mark.parametrize("mode", [0, 1], ids=["fp32-cores", "split-cores"])
+@pytest.mark.parametrize("mode", [0, 1, 3], ids=["fp32-cores", "split-bf16-cores", "split-fp16-cores"])
 def test_g1_g2_on_both_gemm_cores(golden_dir, mode):
-    """The golden vectors hold on the exact fp32 MFMA cores and on the split-bf16 cores."""
+    """The golden vectors hold on the exact fp32 MFMA cores, the split-bf16 cores and the
+    split-fp16 cores."""
     from pointnet_refine_amd import _lib
     lib = _lib.lib()
     old = lib.prh_get_gemm_mode()
@@ -184,9 +185,10 @@ def test_bf16_mode_loose_gate(golden_dir):
 def test_config2_fwd_bwd_two_kernel_families_agree():
     """BASELINE config 2 (B=512, N=1024, fp32 forward+backward, train-mode BN) is too large
     for the CPU oracle, so the full-size check is a cross-check of two independent kernel
-    families on identical inputs: the exact fp32 MFMA cores against the split-bf16 cores
-    (both individually pinned to the golden vectors at B=8).  Outputs within 1e-4, every
-    parameter gradient within 2e-3 rel-L2, BN running statistics within 1e-5 relative."""
+    families on identical inputs: the exact fp32 MFMA cores against the split-bf16 cores and
+    the split-fp16 cores (each individually pinned to the golden vectors at B=8).  Outputs
+    within 1e-4, every parameter gradient within 2e-3 rel-L2, BN running statistics within
+    1e-5 relative."""
     from pointnet_refine_amd import _lib
     lib = _lib.lib()
     sd = P.linerefine_state_dict(0)
@@ -195,7 +197,7 @@ def test_config2_fwd_bwd_two_kernel_families_agree():
     res = {}
     old = lib.prh_get_gemm_mode()
     try:
-        for mode in (0, 1):
+        for mode in (0, 1, 3):
             lib.prh_set_gemm_mode(mode)
             m = _model(sd).train()
             _zero_dropout(m)
@@ -207,15 +209,18 @@ def test_config2_fwd_bwd_two_kernel_families_agree():
             del m, out, loss
     finally:
         lib.prh_set_gemm_mode(old)
-    assert maxdiff(res[0][0], res[1][0]) < 1e-4
-    worst = 0.0
-    for k, g0 in res[0][1].items():
-        if _pre_bn_bias(k):
-            continue
-        worst = max(worst, rel_l2(g0, res[1][1][k]))
-    assert worst < 2e-3, worst
-    for k, v in res[0][2].items():
-        assert maxdiff(v, res[1][2][k]) <= 1e-5 * float(v.abs().max()) + 1e-7, k
+    for other in (1, 3):
+        assert maxdiff(res[0][0], res[other][0]) < 1e-4
+        worst = 0.0
+        for k, g0 in res[0][1].items():
+            if _pre_bn_bias(k):
+                continue
+            worst = max(worst, rel_l2(g0, res[other][1][k]))
+        print(f"mode {other} vs exact fp32 cores: out max|d| {maxdiff(res[0][0], res[other][0]):.2e}, "
+              f"worst gradient rel-L2 {worst:.2e}")
+        assert worst < 2e-3, (other, worst)
+        for k, v in res[0][2].items():
+            assert maxdiff(v, res[other][2][k]) <= 1e-5 * float(v.abs().max()) + 1e-7, (other, k)
 
 
 def test_decoder_layer_standalone_call_contract():
