@@ -184,7 +184,7 @@ static_assert(8 * 32 * EPI_LDW * 4 <= S3_LDS, "epilogue scratch must fit in the 
 
 // ------------------------------------------------------------------ launch helpers
 template <int PRO, int EPI>
-int launch_nt(NTParams p, hipStream_t st, StatInfo* si = nullptr) {
+int launch_nt(NTParams& p, hipStream_t st, StatInfo* si = nullptr) {   // p.amaxA is filled in when measured
   if (p.M <= 0 || p.N <= 0) return PRH_OK;
   if ((p.K & 3) || (PRO != PRO_GATE1 && (p.lda & 3)) || (p.ldw & 3) ||
       (PRO == PRO_BNBWD && (p.lda2 & 3)))
@@ -695,15 +695,18 @@ int prh_linear_backward(const float* x, long ldx, const float* w, const float* d
   linear_bwd_carve(a, lw, rows, k, n);
   if (!a.ok) return fail(PRH_ERR_WORKSPACE, "linear_backward: workspace too small (%zu bytes)", workspace_bytes);
   float *wT = lw.wT, *slab = lw.slab, *cslab = lw.cslab;
+  const float* dy_amax = nullptr;
   if (dx != nullptr) {
     TRY(transpose(w, n, k, wT, st));   // wT [k, n]
     NTParams p; memset(&p, 0, sizeof(p));
     p.A = dy; p.lda = n; p.W = wT; p.ldw = n; p.C = dx; p.ldc = k; p.M = rows; p.N = k; p.K = n;
     p.wprep = lw.wprep;
     TRY((launch_nt<PRO_NONE, EPI_BIAS>(p, st)));
+    dy_amax = p.amaxA;       // measured once for both GEMMs (lives in the head of lw.wprep)
   }
   if (dw != nullptr || db != nullptr) {
     TNParams t; memset(&t, 0, sizeof(t));
+    t.amaxA = dy_amax;
     t.A = dy; t.lda = n; t.B = x; t.ldb = ldx; t.P = rows; t.Mo = n; t.Ni = k;
     TRY((launch_tn<PRO_NONE, PRO_NONE>(t, slab, cslab, dw, (long)k, db, st)));
   }
