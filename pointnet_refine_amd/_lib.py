@@ -16,7 +16,7 @@ _ROOT = os.path.dirname(_HERE)
 # PRH_LIB_PATH: load an alternative build of the same library (kernel-tuning experiments)
 LIB_PATH = os.environ.get("PRH_LIB_PATH") or os.path.join(_HERE, "libpointnet_refine_hip.so")
 _SOURCES = [os.path.join(_HERE, "csrc", f)
-            for f in ("prh_lib.hip", "prh_gemm.hpp", "prh_gemm_s3.hpp", "prh_attn.hpp", "prh_kernels.hpp")]
+            for f in ("prh_lib.hip", "prh_gemm.hpp", "prh_gemm_s3.hpp", "prh_gemm_h2.hpp", "prh_attn.hpp", "prh_kernels.hpp")]
 _HEADER = os.path.join(_ROOT, "include", "pointnet_refine_hip.h")
 
 PRH_MAX_LAYERS = 8

@@ -221,9 +221,103 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[MT][NT], const NTParam
 // `scratch` = this wave's 32*68 floats.  Requires N, ldc, lde1 multiples of 4.
 // ---------------------------------------------------------------------------------------
 constexpr int EPI_LDW = 68;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int EPI, int MT>
-__device__ __forceinline__ void nt_epilogue_vec(f32x16 (&acc)[MT][2], const NTParams& p, int rbase_,
+// The two accumulator layouts of a 128 x 64 wave tile the vector epilogue accepts:
+//   f32x16 acc[MT][2]   : 32x32 MFMA blocks (col = lane&31, row = crow(r, lane>>5))
+//   f32x4  acc[2*MT][4] : 16x16 MFMA blocks (col = lane&15, row = 4*(lane>>4) + r)
+// (a) 32-row block `mt` -> scratch[row][col] (conflict-free 4-B writes), (b) per-column sum and
+// centred M2 of acc+bias over the tile's valid rows -> statistics partials.
+template <int MT>
+__device__ __forceinline__ void epi_block_to_scratch(const f32x16 (&acc)[MT][2], int mt, float* scratch, int lane) {
+  const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) scratch[crow(r, half) * EPI_LDW + nt * 32 + l31] = acc[mt][nt][r];
+}
+template <int MB>
+__device__ __forceinline__ void epi_block_to_scratch(const f32x4 (&acc)[MB][4], int mt, float* scratch, int lane) {
+  const int q = lane >> 4, l15 = lane & 15;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        scratch[(h * 16 + q * 4 + r) * EPI_LDW + nb * 16 + l15] = acc[2 * mt + h][nb][r];
+}
+template <int MT>
+__device__ __forceinline__ void epi_col_stats(const f32x16 (&acc)[MT][2], const NTParams& p, int cbase,
+                                              int mrows, int rb, int lane) {
+  const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int col = cbase + nt * 32 + l31;
+    const bool cok = col < p.N;
+    const float bias = (p.bias != nullptr && cok) ? p.bias[col] : 0.f;
+    float s = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (mt * 32 + crow(r, half) < mrows) s += acc[mt][nt][r] + bias;
+    s += __shfl_xor(s, 32);
+    const int nrows = mrows < 0 ? 0 : (mrows > MT * 32 ? MT * 32 : mrows);
+    const float mean = nrows > 0 ? s / (float)nrows : 0.f;
+    float m2 = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float dlt = acc[mt][nt][r] + bias - mean;
+        if (mt * 32 + crow(r, half) < mrows) m2 = fmaf(dlt, dlt, m2);
+      }
+    m2 += __shfl_xor(m2, 32);
+    if (half == 0 && cok) {
+      p.ws_a[(size_t)rb * p.N + col] = s;
+      p.ws_b[(size_t)rb * p.N + col] = m2;
+    }
+  }
+}
+template <int MB>
+__device__ __forceinline__ void epi_col_stats(const f32x4 (&acc)[MB][4], const NTParams& p, int cbase,
+                                              int mrows, int rb, int lane) {
+  const int q = lane >> 4, l15 = lane & 15;
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+    const int col = cbase + nb * 16 + l15;
+    const bool cok = col < p.N;
+    const float bias = (p.bias != nullptr && cok) ? p.bias[col] : 0.f;
+    float s = 0.f;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (mb * 16 + q * 4 + r < mrows) s += acc[mb][nb][r] + bias;
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    const int nrows = mrows < 0 ? 0 : (mrows > MB * 16 ? MB * 16 : mrows);
+    const float mean = nrows > 0 ? s / (float)nrows : 0.f;
+    float m2 = 0.f;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float dlt = acc[mb][nb][r] + bias - mean;
+        if (mb * 16 + q * 4 + r < mrows) m2 = fmaf(dlt, dlt, m2);
+      }
+    m2 += __shfl_xor(m2, 16);
+    m2 += __shfl_xor(m2, 32);
+    if (q == 0 && cok) {
+      p.ws_a[(size_t)rb * p.N + col] = s;
+      p.ws_b[(size_t)rb * p.N + col] = m2;
+    }
+  }
+}
+
+template <int EPI, int MT, class ACC>
+__device__ __forceinline__ void nt_epilogue_vec(ACC& acc, const NTParams& p, int rbase_,
                                                 int cbase, int rb, int lane, float* scratch) {
   const int half = lane >> 5, l31 = lane & 31;
   const int rbase = __builtin_amdgcn_readfirstlane(rbase_);
@@ -245,37 +339,8 @@ __device__ __forceinline__ void nt_epilogue_vec(f32x16 (&acc)[MT][2], const NTPa
   float* __restrict__ C2b = (EPI == EPI_GATE && p.C2 != nullptr) ? p.C2 + (size_t)rbase * p.ldc2 : nullptr;
   const int ldc2 = (int)p.ldc2;
 
-  if (EPI == EPI_BIAS_STATS) {
-    // statistics straight from the accumulators (column on the lane): sum, then centred M2
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int col = cbase + nt * 32 + l31;
-      const bool cok = col < p.N;
-      const float bias = (p.bias != nullptr && cok) ? p.bias[col] : 0.f;
-      float s = 0.f;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (mt * 32 + crow(r, half) < mrows) s += acc[mt][nt][r] + bias;
-      s += __shfl_xor(s, 32);
-      const int nrows = mrows < 0 ? 0 : (mrows > MT * 32 ? MT * 32 : mrows);
-      const float mean = nrows > 0 ? s / (float)nrows : 0.f;
-      float m2 = 0.f;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float dlt = acc[mt][nt][r] + bias - mean;
-          if (mt * 32 + crow(r, half) < mrows) m2 = fmaf(dlt, dlt, m2);
-        }
-      m2 += __shfl_xor(m2, 32);
-      if (half == 0 && cok) {
-        p.ws_a[(size_t)rb * p.N + col] = s;
-        p.ws_b[(size_t)rb * p.N + col] = m2;
-      }
-    }
-  }
+  // statistics straight from the accumulators (column on the lane): sum, then centred M2
+  if (EPI == EPI_BIAS_STATS) epi_col_stats(acc, p, cbase, mrows, rb, lane);
 
   const bool mask = (p.flags & F_MASK) != 0, accum = (p.flags & F_ACCUM) != 0;
   const bool need_z = (EPI == EPI_DGRAD && (mask || (p.flags & F_STATS) != 0)) || EPI == EPI_GATE;
@@ -294,10 +359,7 @@ __device__ __forceinline__ void nt_epilogue_vec(f32x16 (&acc)[MT][2], const NTPa
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     // accumulator block -> scratch (column layout: conflict-free 128-B rows)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) scratch[crow(r, half) * EPI_LDW + nt * 32 + l31] = acc[mt][nt][r];
+    epi_block_to_scratch(acc, mt, scratch, lane);
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {     // two batches of 4 row groups (register budget)
     // pin each batch's loads to its batch (the operand pointers are read-only/restrict, so the

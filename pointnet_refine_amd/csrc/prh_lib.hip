@@ -17,6 +17,7 @@
 #include "prh_gemm.hpp"
 #include "prh_attn.hpp"
 #include "prh_gemm_s3.hpp"
+#include "prh_gemm_h2.hpp"
 #include "prh_kernels.hpp"
 
 using namespace prh;
@@ -116,6 +117,8 @@ inline int gemm_mode() {
   }
   return g_gemm_mode;
 }
+// PRH_H2_GEN=1 keeps the split-fp16 NT GEMMs on the first-generation core (32x32x16 MFMA, BK 16)
+bool g_h2_gen2 = [] { const char* e = getenv("PRH_H2_GEN"); return !(e && strcmp(e, "1") == 0); }();
 inline const char* core_tag() { return gemm_mode() == 2 ? "b1" : (gemm_mode() == 3 ? "h2" : "s3"); }
 
 // largest |pro(A)| over [rows, cols] into *slot; part: ABSMAX_MAX_BLOCKS floats of scratch
@@ -209,6 +212,30 @@ int launch_nt(NTParams& p, hipStream_t st, StatInfo* si = nullptr) {   // p.amax
         if (p.amaxA == nullptr) {
           TRY_RC((measure_absmax<PRO>(p.A, p.lda, p.A2, p.lda2, p.pa, p.pb, p.pc, p.M, p.K, hdr + 1, hdr + 64, st)));
           p.amaxA = hdr + 1;
+        }
+      }
+      // second-generation split-fp16 core (16x16x32 MFMA, 32-deep k-tiles): plain / BN+ReLU /
+      // gate prologues with a 16-B aligned output; anything else stays on the first generation
+      if constexpr (PRO == PRO_NONE || PRO == PRO_BNRELU || PRO == PRO_GATE1) {
+        const bool vec_ok = ((p.N | (int)p.ldc) & 3) == 0 && (p.E1 == nullptr || ((int)p.lde1 & 3) == 0) &&
+                            (p.flags & F_E1_ROWVEC) == 0 && (p.C2 == nullptr || ((int)p.ldc2 & 3) == 0);
+        const int KT2 = cdiv(p.K, H2_BK);
+        const size_t lds = (size_t)H2_LDS + (PRO == PRO_NONE ? 0 : 2 * (size_t)(KT2 + 2) * H2_BK * 4);
+        if (mode == 3 && g_h2_gen2 && vec_ok && lds <= 160 * 1024) {
+          const long th2 = (long)NTl * 256 * KT2 * 4;
+          hipLaunchKernelGGL(prep_weights_h2_kernel, dim3((unsigned)cdiv(th2, 256)), dim3(256), 0, st, p.W,
+                             p.N, p.K, p.ldw, p.wprep + S3_WHDR, (const float*)hdr);
+          LAUNCH_CHECK();
+          p.tiles_n = NTl;
+          static const int attr_h2 = allow_big_lds(gemm_nt_h2_kernel<PRO, EPI>);
+          if (attr_h2 != PRH_OK) return attr_h2;
+          snprintf(nm, sizeof(nm), "gemm_nt_h2<%d,%d> K=%d N=%d", PRO, EPI, p.K, p.N);
+          ProfScope ps(nm, 2.0 * p.M * (double)p.N * p.K, by, st);
+          hipLaunchKernelGGL((gemm_nt_h2_kernel<PRO, EPI>), dim3((unsigned)(NTl * cdiv(p.M, 256))), dim3(512),
+                             lds, st, p, img);
+          LAUNCH_CHECK();
+          if (si) { si->count = 2 * cdiv(p.M, S3_BM); si->rows = 128; }
+          return PRH_OK;
         }
       }
       hipLaunchKernelGGL(prep_weights_s3_kernel, dim3((unsigned)cdiv(th, 256)), dim3(256), 0, st,
