@@ -103,9 +103,9 @@ int prh_encoder_forward(const prh_encoder_params* prm, const float* ctx, int B, 
  *   d_fused [B,N,out_dim] or NULL, d_gfeat [B,2*out_dim] or NULL (at least one)
  *   d_ctx   [B,N,C] or NULL
  *   training must equal the forward's flag.
- * d_fused is used as scratch and is overwritten. */
+ * The gradient buffers are read only; saved.gate is consumed (overwritten in place). */
 int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B, int N,
-                         int training, float* d_fused, const float* d_gfeat,
+                         int training, const float* d_fused, const float* d_gfeat,
                          const prh_encoder_saved* saved, const prh_encoder_grads* grads,
                          float* d_ctx, void* workspace, size_t workspace_bytes, int device,
                          void* stream);

@@ -655,7 +655,7 @@ void mlp_carve(Arena& a, MlpWS& m, int P, const prh_bn_layer* ly, int L) {
   stack_bwd_scratch_carve(a, m.sc, P, ly, L, 0, 0);
   m.dy_cat = a.f((size_t)P * d.off[L]);
 }
-struct EncWS { StackWS w; StackBwdScratch sc; float* fslab; float* fcslab; float* dy_cat; float* dU; float* gsum_a; float* gsum_b; };
+struct EncWS { StackWS w; StackBwdScratch sc; float* fslab; float* fcslab; float* dy_cat; float* dyf; float* dU; float* gsum_a; float* gsum_b; };
 void enc_carve(Arena& a, EncWS& e, int P, const prh_bn_layer* conv, int cat, int od, bool backward) {
   stack_ws_carve(a, e.w, P, conv, 5, cat > od ? cat : od, od, cat);
   if (!backward) return;
@@ -665,6 +665,7 @@ void enc_carve(Arena& a, EncWS& e, int P, const prh_bn_layer* conv, int cat, int
   e.fslab = a.f(fs > gs ? fs : gs);
   e.fcslab = a.f(fc > gc ? fc : gc);
   e.dy_cat = a.f((size_t)P * cat);
+  e.dyf = a.f((size_t)P * od);
   e.dU = a.f((size_t)P * 64);
   e.gsum_a = a.f(64);
   e.gsum_b = a.f(64);
@@ -902,12 +903,12 @@ int prh_encoder_forward(const prh_encoder_params* prm, const float* ctx, int B, 
 }
 
 int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B, int N,
-                         int training, float* d_fused, const float* d_gfeat,
+                         int training, const float* d_fused, const float* d_gfeat,
                          const prh_encoder_saved* sv, const prh_encoder_grads* gr, float* d_ctx,
                          void* workspace, size_t workspace_bytes, int device, void* stream) {
   TRY(check_encoder(prm));
-  if (!ctx || !sv || !gr || !sv->z_cat || !sv->z_fus || !sv->gate || !d_fused || B <= 0 || N <= 0)
-    return fail(PRH_ERR_ARG, "encoder_backward: bad argument (d_fused buffer and saved.gate are required)");
+  if (!ctx || !sv || !gr || !sv->z_cat || !sv->z_fus || !sv->gate || (!d_fused && !d_gfeat) || B <= 0 || N <= 0)
+    return fail(PRH_ERR_ARG, "encoder_backward: bad argument (a gradient and saved.gate are required)");
   if (d_gfeat && !sv->argmax) return fail(PRH_ERR_ARG, "encoder_backward: d_gfeat needs saved.argmax");
   const int P = B * N;
   HIP_TRY(hipSetDevice(device));
@@ -918,7 +919,7 @@ int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B,
   enc_carve(a, ews, P, prm->conv, cat, od, true);
   StackWS& w = ews.w;
   StackBwdScratch& sc = ews.sc;
-  float *fslab = ews.fslab, *fcslab = ews.fcslab, *dy_cat = ews.dy_cat, *dU = ews.dU;
+  float *fslab = ews.fslab, *fcslab = ews.fcslab, *dy_cat = ews.dy_cat, *dU = ews.dU, *dyf = ews.dyf;
   float *gsum_a = ews.gsum_a, *gsum_b = ews.gsum_b;
   if (!a.ok) return fail(PRH_ERR_WORKSPACE, "encoder_backward: workspace too small (%zu bytes)", workspace_bytes);
   StackDims d = stack_dims(prm->conv, 5);
@@ -927,11 +928,11 @@ int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B,
     TRY(copy_cols(prm->conv[0].w, d.cin0, d.cin0, w.w0pad, d.cin0p, d.cin0p, (size_t)prm->conv[0].cout, st));
   }
 
-  // (1) through F = relu(bn(zf)) * m and the pooling: dy_f -> d_fused (in place),
+  // (1) through F = relu(bn(zf)) * m and the pooling: dy_f -> dyf (workspace),
   //     dG -> saved.gate (in place), fusion-BN backward partials
   hipLaunchKernelGGL(combine_bwd_kernel, dim3(cdiv(P, 64), cdiv(od, 64)), dim3(256), 0, st, d_fused,
                      d_gfeat, sv->argmax, sv->z_fus, sv->gate, sv->bn_scale + cat,
-                     sv->bn_shift + cat, P, N, od, d_fused, w.ws_a, w.ws_b);
+                     sv->bn_shift + cat, P, N, od, dyf, w.ws_a, w.ws_b);
   LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_stage1_kernel, dim3(cdiv(od, 32), BN_SLICES), dim3(256), 0, st, w.ws_a, w.ws_b,
                      cdiv(P, 64), (long)od, od, 64, P, 0, w.stat2);
@@ -948,13 +949,13 @@ int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B,
   StatInfo si5;
   const float* dzf_amax = nullptr;
   const bool matf = dz_in_place(od, (long)od, (long)od);
-  if (matf) {       // split-fp16 mode: d_fused <- dz_f in place (it is scratch from here on)
-    TRY(materialize_dz(d_fused, (long)od, sv->z_fus, (long)od, sc.ca, sc.cb, sc.cc, P, od, sc.hdr, st));
+  if (matf) {       // split-fp16 mode: dyf <- dz_f in place
+    TRY(materialize_dz(dyf, (long)od, sv->z_fus, (long)od, sc.ca, sc.cb, sc.cc, P, od, sc.hdr, st));
     dzf_amax = sc.hdr;
   }
   if (gr->fusion.dw) {
     TNParams t; memset(&t, 0, sizeof(t));
-    t.A = d_fused; t.lda = od; t.A2 = sv->z_fus; t.lda2 = od; t.pa = sc.ca; t.pb = sc.cb; t.pc = sc.cc;
+    t.A = dyf; t.lda = od; t.A2 = sv->z_fus; t.lda2 = od; t.pa = sc.ca; t.pb = sc.cb; t.pc = sc.cc;
     t.B = sv->z_cat; t.ldb = cat; t.qa = sv->bn_scale; t.qb = sv->bn_shift;
     t.P = P; t.Mo = od; t.Ni = cat;
     t.amaxA = dzf_amax;
@@ -966,7 +967,7 @@ int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B,
     TRY(transpose(prm->fusion.w, od, cat, sc.wT, st));   // [cat, od]
     NTParams p; memset(&p, 0, sizeof(p));
     p.amaxA = dzf_amax;
-    p.A = d_fused; p.lda = od; p.A2 = sv->z_fus; p.lda2 = od; p.pa = sc.ca; p.pb = sc.cb; p.pc = sc.cc;
+    p.A = dyf; p.lda = od; p.A2 = sv->z_fus; p.lda2 = od; p.pa = sc.ca; p.pb = sc.cb; p.pc = sc.cc;
     p.W = sc.wT; p.ldw = od; p.M = P; p.N = cat; p.K = od;
     p.C = dy_cat; p.ldc = cat; p.E1 = sv->z_cat; p.lde1 = cat; p.es = sv->bn_scale; p.et = sv->bn_shift;
     p.wprep = w.wprep;

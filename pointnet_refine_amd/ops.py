@@ -289,10 +289,8 @@ class EncoderFn(torch.autograd.Function):
         dev = x.device
         B, N, Cin = x.shape
         out_dim = p2[8].shape[0]
-        if d_fused is None:
-            d_fused = torch.zeros((B, N, out_dim), dtype=torch.float32, device=dev)
-        else:
-            d_fused = d_fused.contiguous().clone() if d_fused.is_contiguous() else d_fused.contiguous()
+        if d_fused is not None:
+            d_fused = d_fused.contiguous()       # read only on the library side
         if d_gfeat is not None:
             if not ctx.has_argmax:
                 raise RuntimeError("encoder backward: gradient for global_feat but no argmax saved")
