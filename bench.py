@@ -34,23 +34,27 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0     # dense v_mfma_f32_32x32x16_bf16
 SPLIT_PRODUCTS = 6                 # bf16 MFMA products per fp32-accurate MAC on the split cores
 SPLIT16_PRODUCTS = 3               # fp16 MFMA products per fp32-accurate MAC on the split-fp16 cores
 DEFAULT_GEMM = "split16"
+PMC_TRAFFIC_FILE = "r01f_pmc_traffic_B4096.json"
 HBM_PEAK_GBS = 8000.0
 
 
 def pmc_traffic(dname, batch, points, mode):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes
-    (profiles/r01_pmc_traffic_B4096.json: FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc
+    (profiles/r01f_pmc_traffic_B4096.json: FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc
     runs of this same command, scripts/pmc_traffic.sh).  Counters cannot be read from inside
-    the benchmark, so this is a lookup valid for the configuration it was taken on; null
-    otherwise."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_B4096.json")
-    if not (os.path.exists(path) and batch == 4096 and points == 1024 and mode == 1):
+    the benchmark, so this is a lookup valid for the configuration it was taken on (default
+    GEMM mode, B=4096, N=1024); null otherwise."""
+    path = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
+    if not (os.path.exists(path) and batch == 4096 and points == 1024 and mode == 3):
         return None
     import re
-    m = re.match(r"gemm_(nt|tn)_s3<(\d),(\d)>", dname)
+    m = re.match(r"gemm_(nt|tn)_h2<(\d),(\d)>", dname)
     if not m:
         return None
-    tmpl = f"prh::gemm_{m.group(1)}_s3_kernel<{m.group(2)}, {m.group(3)}, 3>"
+    if m.group(1) == "tn":      # wgrad: first-generation core, two fp16 planes
+        tmpl = f"prh::gemm_tn_s3_kernel<{m.group(2)}, {m.group(3)}, 2>"
+    else:
+        tmpl = f"prh::gemm_nt_h2_kernel<{m.group(2)}, {m.group(3)}>"
     cands = [r for r in json.load(open(path)) if r["kernel"] == tmpl]
     if not cands:
         return None
@@ -210,7 +214,7 @@ def main():
                 "issued_mfma_tflops": round(achieved * products, 1),
                 "vs_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                 "traffic": pmc_traffic(dname, B, N, lib.prh_get_gemm_mode()),
-                "traffic_source": "profiles/r01_pmc_traffic_B4096.json (rocprofv3 --pmc FETCH_SIZE x2, WRITE_SIZE)",
+                "traffic_source": f"profiles/{PMC_TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE x2, WRITE_SIZE)",
                 "algorithmic_bytes": bytes_,
                 "avg_launch_ms": round(avg_ms, 4), "launches": cnt,
                 "algorithmic_gbs": round(bytes_ / (avg_ms * 1e-3) / 1e9, 1),

@@ -71,6 +71,35 @@ __global__ __launch_bounds__(256) void prep_weights_h2_kernel(const float* __res
   *reinterpret_cast<uint4*>(base + H2_PLANE) = l;
 }
 
+// MFMAs of one 32-deep k-tile for a wave tile of 128 x 64 (row blocks I0..I1-1 of 8): the W
+// fragments of the wave's 4 column blocks stay in registers, the A fragments stream through.
+// (A wgrad core on this loop - 32 rows per k-tile, 16 scalar loads per operand and thread - was
+// built and measured: 13.3 vs 12.9 ms on the fusion wgrad.  The TN core is bound by its
+// column-wise staging, not by the matrix pipe's clock, so it stays on the 32x32x16 loop.)
+template <int I0 = 0, int I1 = 8>
+__device__ __forceinline__ void h2_compute(f32x4 (&acc)[8][4], const char* st, int wm, int wn, int l15,
+                                           int kc) {
+  f16x8 wh[4], wl[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const char* q = st + H2_OPER + h2_off(wn + j * 16 + l15, kc * 8);
+    wh[j] = *reinterpret_cast<const f16x8*>(q);
+    wl[j] = *reinterpret_cast<const f16x8*>(q + H2_PLANE);
+  }
+#pragma unroll
+  for (int i = I0; i < I1; ++i) {
+    const char* q = st + h2_off(wm + i * 16 + l15, kc * 8);
+    const f16x8 ah = *reinterpret_cast<const f16x8*>(q);
+    const f16x8 al = *reinterpret_cast<const f16x8*>(q + H2_PLANE);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[j], acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[j], acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[j], acc[i][j], 0, 0, 0);
+    }
+  }
+}
+
 template <int PRO, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_nt_h2_kernel(const NTParams p,
                                                             const char* __restrict__ Wp) {
@@ -157,29 +186,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_h2_kernel(const NTParams p,
       *reinterpret_cast<uint2*>(q + H2_PLANE) = l;
     }
   };
-  // 96 MFMAs of one k-tile: W fragments of the wave's 4 column blocks stay in registers, the
-  // A fragments of its 8 row blocks stream through
-  auto compute = [&](const char* st) {
-    f16x8 wh[4], wl[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const char* q = st + H2_OPER + h2_off(wn + j * 16 + l15, kc * 8);
-      wh[j] = *reinterpret_cast<const f16x8*>(q);
-      wl[j] = *reinterpret_cast<const f16x8*>(q + H2_PLANE);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const char* q = st + h2_off(wm + i * 16 + l15, kc * 8);
-      const f16x8 ah = *reinterpret_cast<const f16x8*>(q);
-      const f16x8 al = *reinterpret_cast<const f16x8*>(q + H2_PLANE);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[j], acc[i][j], 0, 0, 0);
-      }
-    }
-  };
   // one k-tile: compute tile kt, convert tile kt+1 (set CS) into the other stage, refill set
   // CS^1 (the set tile kt came from) with tile kt+2.  TAIL: no prefetch, ends on vmcnt(0)
   // (the compiler deletes prefetches nobody reads, which would break the counted wait).
@@ -198,7 +204,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_h2_kernel(const NTParams p,
     __builtin_amdgcn_sched_barrier(0);   // DMA strictly before the A loads (vmcnt is in order)
     if (!TAIL) load_tile(kt + 2, ra[CS ^ 1]);
     __builtin_amdgcn_sched_barrier(0);
-    compute(cur);
+    h2_compute(acc, cur, wm, wn, l15, kc);
     store_tile(kt + 1, nxt, ra[CS]);
     // interleave the conversion (~130 VALU) with the 96 MFMAs
 #pragma unroll

@@ -249,7 +249,7 @@ int launch_nt(NTParams& p, hipStream_t st, StatInfo* si = nullptr) {   // p.amax
       if (attr_rc != PRH_OK) return attr_rc;
       if (attr_rc1 != PRH_OK) return attr_rc1;
       if (attr_rc2 != PRH_OK) return attr_rc2;
-      snprintf(nm, sizeof(nm), "gemm_nt_%s<%d,%d> K=%d N=%d", core_tag(), PRO, EPI, p.K, p.N);
+      snprintf(nm, sizeof(nm), "gemm_nt_%s<%d,%d> K=%d N=%d", mode == 3 ? "h2g1" : core_tag(), PRO, EPI, p.K, p.N);
       ProfScope ps(nm, 2.0 * p.M * (double)p.N * p.K, by, st);
       if (mode == 2)
         hipLaunchKernelGGL((gemm_nt_s3_kernel<PRO, EPI, 1>), dim3((unsigned)tiles), dim3(512),

@@ -8,5 +8,5 @@ tail -1 gpurun_out/h2_tests.log
 for g in 2 1; do
   PRH_H2_GEN=$g timeout -k 10 200 python scripts/encoder_bench.py ${1:-1024} 1024 3 > gpurun_out/enc_gen$g.log 2>&1 || { tail -20 gpurun_out/enc_gen$g.log; exit 1; }
   if grep -qi fault gpurun_out/enc_gen$g.log; then echo FAULT; exit 1; fi
-  echo "== NT core generation $g"; grep "gemm_nt_h2\|encoder+proj\|GEMM launches" gpurun_out/enc_gen$g.log
+  echo "== NT core generation $g"; grep "gemm_nt_h2\|gemm_tn_h2\|encoder+proj\|GEMM launches" gpurun_out/enc_gen$g.log
 done
