@@ -629,6 +629,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_s3_kernel(const TNParams p) {
     sB = pow2_scale(load_amax(p.amaxB));
     ka *= sA; kb *= sA; kc *= sA; qa *= sB; qb *= sB;
   }
+  // Plain A operand (PRO_NONE): rows beyond the split and columns beyond Mo need no select -
+  // the buffer descriptor returns 0 for the rows, and the column mask rides on the scale
+  // (finite neighbours x 0).  With A exactly zero there, B needs no row mask either (finite
+  // x 0), and its column mask is the zeroed coefficient pair / scale.
+  constexpr bool LEAN = PROA == PRO_NONE && NPL == 2;
+  const float sAm = aok ? sA : 0.f, sBm = bok ? sB : 0.f;
+  const bool want_cs = p.colsum != nullptr && tile_n == 0;
 
   f32x16 acc[4][2];
 #pragma unroll
@@ -638,7 +645,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_s3_kernel(const TNParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float va[1][8], va2[1][8], vb[1][8];
+  // plain A operand: two staging register sets, loads issued two k-tiles ahead (a k-tile of
+  // MFMAs is far shorter than an HBM round trip; the BN-backward form has a third array to
+  // stage and stays at distance 1)
+  constexpr bool D2 = PROA == PRO_NONE;
+  float va[D2 ? 2 : 1][8], va2[1][8], vb[D2 ? 2 : 1][8];
   float csum = 0.f;
   // Buffer descriptors over this split's rows, based at column m0 / n0: rows at or beyond
   // p_end are out of range and read as 0 (no clamps, no exec-mask branches); per-lane byte
@@ -678,6 +689,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_s3_kernel(const TNParams p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const bool rok = (r0 + j) < p_end;
+      if (LEAN) {
+        ta[j] = xa[j] * sAm;
+        tb[j] = PROB == PRO_BNRELU ? fmaxf(fmaf(xb[j], qa, qb), 0.f) : xb[j] * sBm;
+        if (want_cs) csum += ta[j];
+        continue;
+      }
       float x = xa[j];
       if (PROA == PRO_BNBWD) x = fmaf(ka, xa[j], fmaf(kb, xa2[j], kc));
       else if (PROA == PRO_BNRELU) x = fmaxf(fmaf(xa[j], ka, kb), 0.f);
@@ -712,10 +729,46 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_s3_kernel(const TNParams p) {
   // converted after them.
   if (KT > 0) {
     load_tile(0, va[0], va2[0], vb[0]);
+    if (D2) load_tile(1, va[D2 ? 1 : 0], va2[0], vb[D2 ? 1 : 0]);
     store_tile(0, smem, va[0], va2[0], vb[0]);
   }
   __syncthreads();
-  for (int kt = 0; kt < KT; ++kt) {
+  if constexpr (D2) {
+    // tile t lives in set t & 1: iteration kt converts tile kt+1 (set CS) and refills the set
+    // tile kt came from with tile kt+2
+    auto iter2 = [&](int kt, auto cs) {
+      constexpr int CS = decltype(cs)::value;
+      char* cur = smem + (kt & 1) * S3_STAGE;
+      char* nxt = smem + ((kt + 1) & 1) * S3_STAGE;
+      load_tile(kt + 2, va[CS ^ 1], va2[0], vb[CS ^ 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      s3_compute<NPL, 0, 2>(acc, cur, wm, wn, l31, half);
+      __builtin_amdgcn_sched_barrier(0);
+      s3_compute<NPL, 2, 4>(acc, cur, wm, wn, l31, half);
+      store_tile(kt + 1, nxt, va[CS], va2[0], vb[CS]);
+      if constexpr (NPL == 3) {
+#pragma unroll
+        for (int g = 0; g < 24; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+        }
+      } else if constexpr (NPL == 2) {
+#pragma unroll
+        for (int g = 0; g < 12; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);
+        }
+      }
+      __syncthreads();
+    };
+    int kt = 0;
+    for (; kt + 1 < KT; kt += 2) {
+      iter2(kt, std::integral_constant<int, 1>{});
+      iter2(kt + 1, std::integral_constant<int, 0>{});
+    }
+    if (kt < KT) iter2(kt, std::integral_constant<int, 1>{});
+  }
+  for (int kt = 0; kt < (D2 ? 0 : KT); ++kt) {
     char* cur = smem + (kt & 1) * S3_STAGE;
     char* nxt = smem + ((kt + 1) & 1) * S3_STAGE;
     load_tile(kt + 1, va[0], va2[0], vb[0]);       // past the last tile: out of range -> zeros

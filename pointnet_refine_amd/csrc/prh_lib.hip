@@ -277,7 +277,7 @@ int launch_nt(NTParams& p, hipStream_t st, StatInfo* si = nullptr) {   // p.amax
 
 constexpr int TN_S3_MAX_LD = 4096;   // widest operand row the split TN core accepts
 struct TNPlan { int tiles_m, tiles_n, splits, rows_per_split; bool s3; };
-inline TNPlan tn_plan(int P, int Mo, int Ni, bool allow_s3) {
+inline TNPlan tn_plan(int P, int Mo, int Ni, bool allow_s3, long maxld = TN_S3_MAX_LD) {
   TNPlan pl;
   pl.s3 = allow_s3 && tn_use_s3(P, Mo, Ni);
   const int tile = pl.s3 ? 256 : 128, bk = pl.s3 ? S3_BK : BK;
@@ -285,6 +285,17 @@ inline TNPlan tn_plan(int P, int Mo, int Ni, bool allow_s3) {
   pl.tiles_n = cdiv(Ni, tile);
   const int tiles = pl.tiles_m * pl.tiles_n;
   int s = cdiv(pl.s3 ? 768 : 1024, tiles);
+  if (pl.s3) {
+    // one workgroup per CU: the launch runs in rounds of 256 workgroups, so pick the split
+    // count near the target whose last round is fullest (33 splits x 32 tiles = 4.1 rounds
+    // cost the fusion wgrad 17 % at B=4096)
+    int best = s; double bw = 1e9;
+    for (int c = (s > 3 ? s - 2 : 1); c <= s + 4; ++c) {
+      const double blocks = (double)tiles * c, w = (double)cdiv((long)blocks, 256L) * 256.0 / blocks;
+      if (w < bw - 1e-3) { bw = w; best = c; }
+    }
+    s = best;
+  }
   const int minrows = pl.s3 ? 512 : 128;
   const int smax = cdiv(P, minrows) < 1 ? 1 : cdiv(P, minrows);
   if (s > smax) s = smax;
@@ -294,7 +305,7 @@ inline TNPlan tn_plan(int P, int Mo, int Ni, bool allow_s3) {
   if (rps < bk) rps = bk;
   // the split core addresses a split's rows through 32-bit buffer offsets: keep
   // rows_per_split * leading_dimension * 4 below 2^31 for any ld <= TN_S3_MAX_LD
-  const int cap = (int)((2147483647L / (4L * TN_S3_MAX_LD)) / bk * bk);
+  const int cap = (int)((2147483647L / (4L * (maxld < 4 ? 4 : maxld))) / bk * bk);
   if (pl.s3 && rps > cap) rps = cap;
   pl.splits = cdiv(P, rps) < 1 ? 1 : cdiv(P, rps);
   pl.rows_per_split = rps;
@@ -302,14 +313,13 @@ inline TNPlan tn_plan(int P, int Mo, int Ni, bool allow_s3) {
 }
 // floats behind a slab: [0] largest |proA(A)|, [1] largest |proB(B)|, [64..) per-block maxima
 constexpr int TN_HDR = S3_HDR_FLOATS;
-inline size_t tn_slab_floats(int P, int Mo, int Ni) {   // upper bound over both cores
+inline size_t tn_splits_bound(int P, int Mo, int Ni) {   // over both cores and any leading dimension
   const size_t a = (size_t)tn_plan(P, Mo, Ni, true).splits, b = (size_t)tn_plan(P, Mo, Ni, false).splits;
-  return (a > b ? a : b) * Mo * Ni + TN_HDR;
+  const size_t c = (size_t)tn_plan(P, Mo, Ni, true, 4).splits;
+  return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
-inline size_t tn_colsum_floats(int P, int Mo, int Ni) {
-  const size_t a = (size_t)tn_plan(P, Mo, Ni, true).splits, b = (size_t)tn_plan(P, Mo, Ni, false).splits;
-  return (a > b ? a : b) * Mo;
-}
+inline size_t tn_slab_floats(int P, int Mo, int Ni) { return tn_splits_bound(P, Mo, Ni) * Mo * Ni + TN_HDR; }
+inline size_t tn_colsum_floats(int P, int Mo, int Ni) { return tn_splits_bound(P, Mo, Ni) * Mo; }
 
 // C[Mo,Ni] (ld ldc) = proA(A)^T proB(B); colsum_out[Mo] = column sums of proA(A) (optional)
 template <int PROA, int PROB>
@@ -317,7 +327,9 @@ int launch_tn(TNParams& p, float* slab, float* colsum_slab, float* C, long ldc, 
               hipStream_t st) {   // p.amaxA / p.amaxB are filled in when the fp16-plane core measured them
   if (p.Mo <= 0 || p.Ni <= 0) return PRH_OK;
   const bool ld_ok = p.lda <= TN_S3_MAX_LD && p.ldb <= TN_S3_MAX_LD && p.lda2 <= TN_S3_MAX_LD;
-  TNPlan pl = tn_plan(p.P, p.Mo, p.Ni, PROB != PRO_GATE1 && ld_ok);
+  long maxld = p.lda > p.ldb ? p.lda : p.ldb;
+  if (PROA == PRO_BNBWD && p.lda2 > maxld) maxld = p.lda2;
+  TNPlan pl = tn_plan(p.P, p.Mo, p.Ni, PROB != PRO_GATE1 && ld_ok, maxld);
   if (!pl.s3 && ((p.Mo & 3) || (p.Ni & 3) || (p.lda & 3) || (PROB != PRO_GATE1 && (p.ldb & 3))))
     return fail(PRH_ERR_ARG, "gemm_tn: Mo/Ni/lda/ldb must be multiples of 4 (Mo=%d Ni=%d)", p.Mo,
                 p.Ni);

@@ -1,12 +1,9 @@
 #!/bin/bash
-# GEMM/encoder/model parity in the default mode, then per-launch durations of the encoder with
-# the second- and first-generation split-fp16 NT cores
+# GEMM/encoder/model parity in the default mode, then per-launch durations of the encoder
 set -o pipefail
 mkdir -p gpurun_out
 timeout -k 10 600 python -m pytest tests/test_gemm_gpu.py tests/test_encoder_gpu.py tests/test_model_gpu.py -q -m gpu -x > gpurun_out/h2_tests.log 2>&1 || { grep -v "^$" gpurun_out/h2_tests.log | tail -60; exit 1; }
 tail -1 gpurun_out/h2_tests.log
-for g in 2 1; do
-  PRH_H2_GEN=$g timeout -k 10 200 python scripts/encoder_bench.py ${1:-1024} 1024 3 > gpurun_out/enc_gen$g.log 2>&1 || { tail -20 gpurun_out/enc_gen$g.log; exit 1; }
-  if grep -qi fault gpurun_out/enc_gen$g.log; then echo FAULT; exit 1; fi
-  echo "== NT core generation $g"; grep "gemm_nt_h2\|gemm_tn_h2\|encoder+proj\|GEMM launches" gpurun_out/enc_gen$g.log
-done
+timeout -k 10 200 python scripts/encoder_bench.py ${1:-1024} 1024 3 > gpurun_out/enc.log 2>&1 || { tail -20 gpurun_out/enc.log; exit 1; }
+if grep -qi fault gpurun_out/enc.log; then echo FAULT; exit 1; fi
+cat gpurun_out/enc.log
