@@ -113,7 +113,7 @@ int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B,
 /* nn.Linear forward y = act(x W^T + b): context_proj (src/model.py:147,194) and any
  * other Linear on the path.  x [rows,k] (ld ldx), w [n,k], y [rows,n]; relu: 0/1.
  * k and ldx must be multiples of 4.  workspace (may be NULL: exact fp32 MFMA core only) holds the
- * split-bf16 weight image of the large-GEMM core. */
+ * split weight image (and the operand-scale words) of the large-GEMM cores. */
 size_t prh_linear_forward_workspace_bytes(int rows, int k, int n);
 int prh_linear_forward(const float* x, long ldx, const float* w, const float* b, float* y,
                        int rows, int k, int n, int relu, void* workspace, size_t workspace_bytes,
@@ -158,15 +158,18 @@ int prh_attn_backward(const float* q, long ldq, const float* k, long ldk, const 
                       int N, int H, float scale, float dropout_p, unsigned seed, int device,
                       void* stream);
 
-/* GEMM core selection: environment PRH_GEMM=fp32 forces the exact fp32 MFMA cores
- * (v_mfma_f32_32x32x2_f32) everywhere; the default routes large GEMMs to the split-bf16
- * cores (three bf16 planes per fp32 operand, six v_mfma_f32_32x32x16_bf16 products,
- * fp32-level error).  Both are checked against the oracle at the same 1e-4 gate.
- * PRH_GEMM=bf16 / mode 2 is the opt-in REDUCED-PRECISION mode (BASELINE config 3): the same
- * cores with plain bf16 operands, one MFMA product, fp32 accumulate and fp32 storage; its
- * parity gate is 5e-2, not 1e-4.
- * prh_set_gemm_mode(0 = fp32, 1 = split, 2 = bf16) overrides the environment at run time
- * (process-wide; set it before launching work, not concurrently with it). */
+/* GEMM core selection (environment PRH_GEMM, or prh_set_gemm_mode at run time):
+ *   split16 / 3 (default): large GEMMs on the split-fp16 cores - two fp16 planes per fp32 operand
+ *            placed by a power-of-two scale from the operand's largest magnitude, three
+ *            v_mfma_f32_16x16x32_f16 / 32x32x16 products, fp32 accumulation, fp32-level error;
+ *   split / 1: split-bf16 cores - three bf16 planes, six v_mfma_f32_32x32x16_bf16 products,
+ *            fp32-level error with no range assumption;
+ *   fp32 / 0: the exact fp32 MFMA cores (v_mfma_f32_32x32x2_f32) everywhere.
+ * All three are checked against the oracle at the same 1e-4 gate.
+ *   bf16 / 2: opt-in REDUCED-PRECISION mode (BASELINE config 3): plain bf16 operands, one MFMA
+ *            product, fp32 accumulate and fp32 storage; its parity gate is 5e-2, not 1e-4.
+ * The mode is process-wide; set it before launching work, not concurrently with it, and keep
+ * it unchanged between a forward call and its backward. */
 int prh_set_gemm_mode(int mode);
 int prh_get_gemm_mode(void);
 

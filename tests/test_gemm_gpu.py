@@ -120,3 +120,44 @@ def test_bf16_mode_is_reduced_precision_but_sane():
     finally:
         lib.prh_set_gemm_mode(old)
     assert 1e-4 < err < 1e-2, err
+
+
+def test_split16_operand_scales():
+    """The split-fp16 core places each operand by a power-of-two scale taken from its largest
+    magnitude: results must not depend on the operands' absolute magnitudes (1e-12 .. 1e+10),
+    an all-zero operand gives exact zeros, and a single outlier 1e6 times larger than the rest
+    costs the small entries precision only relative to the outlier's row scale (rel-L2 of the
+    whole product stays at fp32 level)."""
+    from pointnet_refine_amd import _lib
+    lib = _lib.lib()
+    m, n, k = 2048, 512, 1024
+    g = torch.Generator(device="cuda").manual_seed(11)
+    a0 = torch.randn(m, k, device="cuda", generator=g)
+    w0 = torch.randn(n, k, device="cuda", generator=g)
+    nb = lib.prh_linear_forward_workspace_bytes(m, k, n)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    old = lib.prh_get_gemm_mode()
+    try:
+        lib.prh_set_gemm_mode(3)
+
+        def run(a, w):
+            c = torch.full((m, n), float("nan"), device="cuda")
+            assert lib.prh_test_gemm_nt(_p(a), _p(w), _p(c), m, n, k, _p(ws), nb, 0, st) == 0
+            return c
+
+        for sa, sw in ((1.0, 1.0), (1e-12, 1e10), (3e7, 2e-9), (1e-6, 1e-6)):
+            a, w = a0 * sa, w0 * sw
+            ref = a.double() @ w.double().t()
+            err = float((run(a, w).double() - ref).norm() / ref.norm())
+            assert err < 1e-6, (sa, sw, err)
+        assert float(run(torch.zeros_like(a0), w0).abs().max()) == 0.0
+        a = a0.clone()
+        a[7, 3] = 1e6
+        ref = a.double() @ w0.double().t()
+        c = run(a, w0).double()
+        assert float((c - ref).norm() / ref.norm()) < 1e-6
+        rows = torch.arange(m, device="cuda") != 7          # rows without the outlier: error relative
+        assert float((c - ref)[rows].abs().max()) < 1e-6 * 1e6 * 2 ** -9   # to outlier * 2^-22-ish floor
+    finally:
+        lib.prh_set_gemm_mode(old)
