@@ -158,6 +158,27 @@ int prh_attn_backward(const float* q, long ldq, const float* k, long ldk, const 
                       int N, int H, float scale, float dropout_p, unsigned seed, int device,
                       void* stream);
 
+/* Per-line context builder: the crop / weight / sample / centre step of
+ * LaneRefineDataset.__getitem__ (src/dataset.py:210-234) and process_single_line
+ * (inference_whole_scene.py:98-121), weighted_sampling (src/dataset.py:78-130), batched over the
+ * lines of one scene.
+ *   cloud  [npts,4] xyz + intensity          dense [n_lines,n_dense,3] polyline resampled to
+ *   line   [n_lines,m,3] resampled to m pts        n_dense points (200 in the reference)
+ *   out    [n_lines,n_samples,4] xyz centred on the line's mean, raw intensity
+ *   counts [n_lines] points inside the tube (before the max_candidates cap)
+ *   dbg_weights [n_lines,max_candidates] or NULL: unnormalised sampling weights of the
+ *               candidates in cloud order (lines with counts > n_samples only)
+ * Crop masks and weights match the reference to fp32 rounding; the draws replace
+ * numpy.random.choice by hashing (seed, line, point index): same distribution, not the same
+ * sample.  Deterministic for a given seed.  Lines with more than max_candidates points in the
+ * tube use the first max_candidates in cloud order (counts still reports the true number). */
+size_t prh_context_workspace_bytes(int npts, int n_lines, int max_candidates);
+int prh_context_build(const float* cloud, int npts, const float* dense, int n_dense, const float* line,
+                      int m, int n_lines, float radius, float decay_scale, int n_samples,
+                      int max_candidates, unsigned long long seed, float* out, int32_t* counts,
+                      float* dbg_weights, void* workspace, size_t workspace_bytes, int device,
+                      void* stream);
+
 /* GEMM core selection (environment PRH_GEMM, or prh_set_gemm_mode at run time):
  *   split16 / 3 (default): large GEMMs on the split-fp16 cores - two fp16 planes per fp32 operand
  *            placed by a power-of-two scale from the operand's largest magnitude, three

@@ -57,6 +57,7 @@ EXPORTS = [
     "prh_test_gemm_nt", "prh_test_gemm_tn_workspace_bytes", "prh_test_gemm_tn",
     "prh_profile_enable", "prh_profile_count", "prh_profile_reset", "prh_profile_read",
     "prh_attn_forward", "prh_attn_backward",
+    "prh_context_workspace_bytes", "prh_context_build",
     "prh_set_gemm_mode", "prh_get_gemm_mode",
     "prh_last_error", "prh_version",
 ]
@@ -119,6 +120,11 @@ def _bind(lib):
     lib.prh_attn_backward.restype = i
     lib.prh_attn_backward.argtypes = [vp, lg, vp, lg, vp, lg, vp, lg, vp, vp, lg, vp, lg, vp, lg, vp, lg,
                                       i, i, i, i, f, f, C.c_uint, i, vp]
+    lib.prh_context_workspace_bytes.restype = C.c_size_t
+    lib.prh_context_workspace_bytes.argtypes = [i, i, i]
+    lib.prh_context_build.restype = i
+    lib.prh_context_build.argtypes = [vp, i, vp, i, vp, i, i, f, f, i, i, C.c_ulonglong, vp, vp, vp, vp,
+                                      C.c_size_t, i, vp]
     lib.prh_set_gemm_mode.restype = i
     lib.prh_set_gemm_mode.argtypes = [i]
     lib.prh_get_gemm_mode.restype = i

@@ -1,0 +1,80 @@
+"""GPU context builder: the per-line crop / weight / sample / centre step of
+the reference's ``LaneRefineDataset.__getitem__`` (src/dataset.py:205-253) and
+``process_single_line`` (inference_whole_scene.py:94-131), batched over all polylines of a scene
+on the HIP path (``prh_context_build``).  Host side: polyline resampling (tiny, numpy).
+
+    cloud = torch.from_numpy(pcd_points).float().cuda()            # (P,4) xyz + intensity
+    ctx, noisy, centres, counts = build_contexts(cloud, raw_lines, num_context_points=1024,
+                                                 crop_radius=0.3, seed=epoch)
+    offsets = model(ctx, noisy)                                     # (6,L,32,3)
+    refined = noisy + centres[:, None, :] + offsets[-1]             # original coordinates
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+DENSE_POINTS = 200          # src/dataset.py:214: tube continuity needs ~0.25 m spacing
+
+
+def resample_polyline(points, num_points=32):
+    """Arc-length resampling by linear interpolation (reference: src/dataset.py:8-29)."""
+    points = np.asarray(points, dtype=np.float64).reshape(-1, 3)
+    if len(points) < 2:
+        return np.zeros((num_points, 3))
+    cum = np.concatenate(([0.0], np.cumsum(np.linalg.norm(np.diff(points, axis=0), axis=1))))
+    t = np.linspace(0.0, cum[-1], num_points)
+    return np.stack([np.interp(t, cum, points[:, k]) for k in range(3)], axis=1)
+
+
+def build_contexts_resampled(cloud, dense, line, num_context_points=1024, crop_radius=0.3,
+                             decay_scale=2.0, seed=0, max_candidates=None, return_weights=False):
+    """cloud (P,4), dense (L,D,3), line (L,M,3) float32 CUDA tensors ->
+    context (L,N,4) centred on each line's mean, counts (L,) int32 [, weights (L,max_candidates)]."""
+    for t, name in ((cloud, "cloud"), (dense, "dense"), (line, "line")):
+        if not (t.is_cuda and t.dtype == torch.float32):
+            raise RuntimeError(f"build_contexts: {name} must be a float32 CUDA tensor (there is no CPU fallback)")
+    cloud, dense, line = cloud.contiguous(), dense.contiguous(), line.contiguous()
+    if cloud.dim() != 2 or cloud.shape[1] != 4:
+        raise RuntimeError(f"build_contexts: cloud must be (P,4), got {tuple(cloud.shape)}")
+    if dense.dim() != 3 or line.dim() != 3 or dense.shape[0] != line.shape[0] or dense.shape[2] != 3 or line.shape[2] != 3:
+        raise RuntimeError("build_contexts: dense (L,D,3) and line (L,M,3) expected")
+    dev = cloud.device
+    n_lines, n = dense.shape[0], int(num_context_points)
+    npts = cloud.shape[0]
+    if max_candidates is None:
+        max_candidates = max(4 * n, 8192)
+    max_candidates = max(int(max_candidates), n + 1)
+    out = torch.empty((n_lines, n, 4), dtype=torch.float32, device=dev)
+    counts = torch.empty((n_lines,), dtype=torch.int32, device=dev)
+    weights = torch.zeros((n_lines, max_candidates), dtype=torch.float32, device=dev) if return_weights else None
+    if n_lines == 0:
+        return (out, counts, weights) if return_weights else (out, counts)
+    lib = L.lib()
+    nb = lib.prh_context_workspace_bytes(npts, n_lines, max_candidates)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else None
+    L.check(lib.prh_context_build(p(cloud), npts, p(dense), dense.shape[1], p(line), line.shape[1], n_lines,
+                                  float(crop_radius), float(decay_scale), n, max_candidates,
+                                  C.c_ulonglong(int(seed) & 0xFFFFFFFFFFFFFFFF), p(out), p(counts), p(weights),
+                                  p(ws), nb, dev.index, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+            "prh_context_build")
+    return (out, counts, weights) if return_weights else (out, counts)
+
+
+def build_contexts(cloud, raw_lines, num_line_points=32, num_context_points=1024, crop_radius=0.3,
+                   decay_scale=2.0, seed=0, max_candidates=None):
+    """raw_lines: sequence of (n_i,3) polylines in scene coordinates.  Returns
+    context (L,N,4), noisy_line (L,M,3) centred, centres (L,3), counts (L,) - the model inputs of
+    inference_whole_scene.py:98-126 for every line at once."""
+    dev = cloud.device
+    dense = np.stack([resample_polyline(l, DENSE_POINTS) for l in raw_lines]) if len(raw_lines) else np.zeros((0, DENSE_POINTS, 3))
+    line = np.stack([resample_polyline(l, num_line_points) for l in raw_lines]) if len(raw_lines) else np.zeros((0, num_line_points, 3))
+    dense_t = torch.from_numpy(dense).float().to(dev)
+    line_t = torch.from_numpy(line).float().to(dev)
+    ctx, counts = build_contexts_resampled(cloud, dense_t, line_t, num_context_points, crop_radius, decay_scale,
+                                           seed, max_candidates)
+    centres = line_t.mean(dim=1)
+    return ctx, line_t - centres[:, None, :], centres, counts

@@ -18,6 +18,7 @@
 #include "prh_attn.hpp"
 #include "prh_gemm_s3.hpp"
 #include "prh_gemm_h2.hpp"
+#include "prh_context.hpp"
 #include "prh_kernels.hpp"
 
 using namespace prh;
@@ -1023,6 +1024,57 @@ int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B,
       LAUNCH_CHECK();
     }
   }
+  return PRH_OK;
+}
+
+// ------------------------------------------------------------------ context builder (row f2)
+struct CtxWS { int* blkcnt; int* blkoff; int* cand; unsigned* keys; };
+void ctx_carve(Arena& a, CtxWS& w, int npts, int L, int max_cand) {
+  const size_t nblk = (size_t)cdiv(npts, 256);
+  w.blkcnt = (int*)a.f(nblk * L);
+  w.blkoff = (int*)a.f(nblk * L);
+  w.cand = (int*)a.f((size_t)L * max_cand);
+  w.keys = (unsigned*)a.f((size_t)L * max_cand);
+}
+size_t prh_context_workspace_bytes(int npts, int n_lines, int max_candidates) {
+  if (npts < 0 || n_lines <= 0 || max_candidates <= 0) return 0;
+  Arena a; CtxWS w;
+  ctx_carve(a, w, npts, n_lines, max_candidates);
+  return a.off + 256;
+}
+int prh_context_build(const float* cloud, int npts, const float* dense, int n_dense, const float* line,
+                      int m, int n_lines, float radius, float decay_scale, int n_samples,
+                      int max_candidates, unsigned long long seed, float* out, int32_t* counts,
+                      float* dbg_weights, void* workspace, size_t workspace_bytes, int device,
+                      void* stream) {
+  if (!dense || !line || !out || !counts || (npts > 0 && !cloud) || npts < 0 || n_lines <= 0 || n_samples <= 0)
+    return fail(PRH_ERR_ARG, "context_build: bad argument");
+  if (n_dense < 1 || n_dense > CTX_MAX_DENSE || m < 1 || m > CTX_MAX_LINE)
+    return fail(PRH_ERR_ARG, "context_build: n_dense must be 1..%d and m 1..%d", CTX_MAX_DENSE, CTX_MAX_LINE);
+  if (n_lines > 65535) return fail(PRH_ERR_ARG, "context_build: at most 65535 lines per call");
+  if (max_candidates < n_samples + 1)
+    return fail(PRH_ERR_ARG, "context_build: max_candidates must exceed n_samples");
+  if (!(decay_scale > 0.f) || !(radius >= 0.f)) return fail(PRH_ERR_ARG, "context_build: radius/decay_scale");
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  Arena a(workspace, workspace_bytes);
+  CtxWS w;
+  ctx_carve(a, w, npts, n_lines, max_candidates);
+  if (!a.ok) return fail(PRH_ERR_WORKSPACE, "context_build: workspace too small (%zu bytes)", workspace_bytes);
+  const int nblk = cdiv(npts, 256) < 1 ? 1 : cdiv(npts, 256);
+  const float r2 = radius * radius;
+  hipLaunchKernelGGL((ctx_crop_kernel<false>), dim3(nblk, n_lines), dim3(256), 0, st, cloud, npts, dense, n_dense,
+                     r2, nblk, w.blkcnt, (const int*)nullptr, (int*)nullptr, max_candidates);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(ctx_scan_kernel, dim3(n_lines), dim3(256), 0, st, w.blkcnt, nblk, w.blkoff, counts);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL((ctx_crop_kernel<true>), dim3(nblk, n_lines), dim3(256), 0, st, cloud, npts, dense, n_dense, r2,
+                     nblk, w.blkcnt, (const int*)w.blkoff, w.cand, max_candidates);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(ctx_select_kernel, dim3(n_lines), dim3(256), 0, st, cloud, line, m, (const int*)counts,
+                     (const int*)w.cand, max_candidates, decay_scale, n_samples, (uint64_t)seed, w.keys, out,
+                     dbg_weights);
+  LAUNCH_CHECK();
   return PRH_OK;
 }
 

@@ -1,0 +1,115 @@
+"""Row f2 on the GPU: prh_context_build against the oracle / the reference-generated fixture.
+Crop sets and weights are compared exactly (fp32 rounding); the draws are compared in
+distribution (the reference uses numpy.random.choice, the HIP path hashes (seed, line, point))."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import context_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(cloud, dense, line, n, radius, decay=2.0, seed=0, max_candidates=None, weights=False):
+    from pointnet_refine_amd.context import build_contexts_resampled
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    return build_contexts_resampled(t(cloud), t(dense), t(line), n, radius, decay, seed, max_candidates, weights)
+
+
+def test_fixture_crop_weights_and_sample_validity(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g7_context.npz"))
+    cloud = g["cloud"]
+    for i in range(4):
+        radius, decay, n, _ = g[f"cfg{i}"]
+        n = int(n)
+        dense, line, mask, dist = g[f"dense{i}"], g[f"line{i}"], g[f"mask{i}"], g[f"dist{i}"]
+        assert not (np.abs(dist - radius) < 1e-5).any()        # no point on the fp32 rounding boundary
+        ctx, counts, w = _build(cloud, dense[None], line[None], n, radius, decay, seed=5, weights=True)
+        k = int(mask.sum())
+        assert int(counts[0]) == k                              # same crop set size ...
+        cands = cloud[mask]
+        centre = line.astype(np.float32).mean(0)
+        rows = ctx[0].cpu().numpy()
+        assert rows.shape == (n, 4)
+        cand_keys = {tuple(np.round(np.append(c[:3] - centre, c[3]), 4)) for c in cands}
+        assert all(tuple(np.round(r, 4)) in cand_keys for r in rows)      # ... and only its members
+        if k > n:
+            assert np.allclose(w[0, :k].cpu().numpy(), g[f"weights{i}"], rtol=3e-5, atol=1e-7)   # cloud order
+            assert len({tuple(np.round(r, 4)) for r in rows}) == n                                 # no repeats
+        else:
+            assert k == 1 and np.allclose(rows, np.append(cands[0, :3] - centre, cands[0, 3]), atol=1e-5)
+
+
+def test_empty_crop_and_determinism():
+    rng = np.random.default_rng(1)
+    cloud = np.column_stack([rng.uniform(-5, 5, (3000, 3)) * [1, 1, 0.02], rng.uniform(0, 50, 3000)])
+    raw = np.array([[-5.0, 0.3, 0.0], [0.0, -0.2, 0.0], [5.0, 0.4, 0.0]])
+    far = raw + [0.0, 300.0, 0.0]
+    dense = np.stack([O.arc_resample(raw, 200), O.arc_resample(far, 200)])
+    line = np.stack([O.arc_resample(raw, 32), O.arc_resample(far, 32)])
+    a, ca = _build(cloud, dense, line, 128, 0.8, seed=11)
+    b, cb = _build(cloud, dense, line, 128, 0.8, seed=11)
+    c, _ = _build(cloud, dense, line, 128, 0.8, seed=12)
+    assert torch.equal(a, b) and torch.equal(ca, cb)            # deterministic for a seed
+    assert not torch.equal(a[0], c[0])                          # another seed, another draw
+    assert int(ca[1]) == 0                                      # nothing near the far line:
+    centre = line[1].astype(np.float32).mean(0)                 # zeros minus the centre (src/dataset.py:87-88,231-232)
+    assert np.allclose(a[1, :, :3].cpu().numpy(), -centre, atol=1e-4) and float(a[1, :, 3].abs().max()) == 0.0
+    assert int(ca[0]) == int(O.crop_mask(cloud.astype(np.float32), dense[0], 0.8).sum())
+
+
+def test_sampling_distribution_matches_numpy_choice():
+    """Inclusion frequencies of weighted draws without replacement: 4096 independent GPU draws
+    (one 'line' each) against numpy.random.choice(p=w/sum w, replace=False) - the reference's call."""
+    rng = np.random.default_rng(3)
+    K, N, T = 24, 6, 4096
+    xyz = np.column_stack([np.linspace(-2, 2, K), rng.uniform(0, 3.0, K), np.zeros(K)])
+    cloud = np.column_stack([xyz, rng.uniform(0, 100, K)]).astype(np.float32)
+    raw = np.array([[-2.0, 0.0, 0.0], [2.0, 0.0, 0.0]])
+    dense, line = O.arc_resample(raw, 200), O.arc_resample(raw, 32)
+    decay = 0.7
+    ctx, counts = _build(cloud, np.repeat(dense[None], T, 0), np.repeat(line[None], T, 0), N, 10.0, decay, seed=99)
+    assert int(counts.min()) == K and int(counts.max()) == K
+    centre = line.astype(np.float32).mean(0)
+    rows = ctx.cpu().numpy() + np.append(centre, 0.0)
+    idx = np.abs(rows[:, :, None, 0] - cloud[None, None, :, 0]).argmin(-1)        # x is unique per point
+    freq = np.bincount(idx.ravel(), minlength=K) / T
+    w = O.sampling_weights(cloud, line, decay)
+    p = w / w.sum()
+    ref = np.zeros(K)
+    R = 20000
+    for _ in range(R):
+        ref[rng.choice(K, N, replace=False, p=p)] += 1
+    ref /= R
+    sigma = np.sqrt(ref * (1 - ref) * (1.0 / T + 1.0 / R)) + 1e-3
+    assert np.all(np.abs(freq - ref) < 4.5 * sigma), (freq, ref)
+    assert abs(freq.sum() - N) < 1e-9                          # exactly N distinct points per draw
+    # K <= N: uniform with replacement
+    ctx2, _ = _build(cloud[:5], np.repeat(dense[None], 512, 0), np.repeat(line[None], 512, 0), 40, 10.0, decay, seed=5)
+    rows2 = ctx2.cpu().numpy() + np.append(centre, 0.0)
+    idx2 = np.abs(rows2[:, :, None, 0] - cloud[None, None, :5, 0]).argmin(-1)
+    f2 = np.bincount(idx2.ravel(), minlength=5) / idx2.size
+    assert np.all(np.abs(f2 - 0.2) < 0.02)
+
+
+def test_whole_scene_size_and_error_behaviour():
+    """Config-5 shape: 100k-point cloud, 512 polylines, N=1024, r=0.3 (inference_whole_scene.py:20-22)."""
+    from pointnet_refine_amd.context import build_contexts
+    rng = np.random.default_rng(8)
+    P, L = 100_000, 512
+    lines = []
+    for i in range(L):
+        x = np.sort(rng.uniform(-60, 60, 6))
+        lines.append(np.stack([x, rng.uniform(-40, 40) + 0.2 * np.sin(x / 9), rng.normal(0, 0.02, 6)], 1))
+    xyz = np.stack([rng.uniform(-60, 60, P), rng.uniform(-40, 40, P), rng.normal(0, 0.05, P)], 1)
+    cloud = np.column_stack([xyz, np.clip(rng.exponential(12, P), 0, 255)]).astype(np.float32)
+    ct = torch.from_numpy(cloud).cuda()
+    ctx, noisy, centres, counts = build_contexts(ct, lines, 32, 1024, 0.3, 2.0, seed=1)
+    assert ctx.shape == (L, 1024, 4) and noisy.shape == (L, 32, 3) and centres.shape == (L, 3)
+    assert bool(torch.isfinite(ctx).all())
+    for i in (0, 100, 511):
+        assert int(counts[i]) == int(O.crop_mask(cloud, O.arc_resample(lines[i], 200), 0.3).sum())
+    with pytest.raises(RuntimeError):
+        build_contexts(ct.cpu(), lines[:2])
