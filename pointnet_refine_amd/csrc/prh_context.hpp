@@ -51,25 +51,56 @@ __device__ __forceinline__ float ctx_min_d2(float x, float y, float z, const flo
   return best;
 }
 
+// pass 0: bounding box of each line's tube (polyline samples +- radius)
+__global__ __launch_bounds__(64) void ctx_bbox_kernel(const float* __restrict__ dense, int nd, float radius,
+                                                      float* __restrict__ box) {
+  const int line = blockIdx.x, lane = threadIdx.x;
+  float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  for (int j = lane; j < nd; j += 64)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v = dense[((size_t)line * nd + j) * 3 + c];
+      lo[c] = fminf(lo[c], v); hi[c] = fmaxf(hi[c], v);
+    }
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+    for (int o = 32; o > 0; o >>= 1) {
+      lo[c] = fminf(lo[c], __shfl_xor(lo[c], o));
+      hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], o));
+    }
+  const float r = radius * 1.0001f + 1e-6f;
+  if (lane < 3) { box[line * 6 + lane] = lo[lane] - r; box[line * 6 + 3 + lane] = hi[lane] + r; }
+}
+
 // pass 1 (FILL = false): per (256-point block, line) number of points inside the tube;
 // pass 3 (FILL = true): the same test again, points written to cand[line][offset + rank]
 template <bool FILL>
 __global__ __launch_bounds__(256) void ctx_crop_kernel(const float* __restrict__ cloud, int npts,
                                                        const float* __restrict__ dense, int nd,
-                                                       float r2, int nblk, int* __restrict__ blkcnt,
+                                                       const float* __restrict__ box, float r2, int nblk,
+                                                       int* __restrict__ blkcnt,
                                                        const int* __restrict__ blkoff,
                                                        int* __restrict__ cand, int max_cand) {
   __shared__ float pts[3 * CTX_MAX_DENSE];
   __shared__ int wcnt[4];
   const int line = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+  const int p = blk * 256 + tid;
+  // the tube's bounding box first: most (point, line) pairs - and most whole blocks - end here
+  const float* bx = box + line * 6;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  bool near = false;
+  if (p < npts) {
+    v = *reinterpret_cast<const float4*>(cloud + (size_t)p * 4);
+    near = v.x >= bx[0] && v.x <= bx[3] && v.y >= bx[1] && v.y <= bx[4] && v.z >= bx[2] && v.z <= bx[5];
+  }
+  if (!__syncthreads_or(near)) {
+    if (!FILL && tid == 0) blkcnt[(size_t)line * nblk + blk] = 0;
+    return;
+  }
   for (int i = tid; i < 3 * nd; i += 256) pts[i] = dense[(size_t)line * nd * 3 + i];
   __syncthreads();
-  const int p = blk * 256 + tid;
   bool in = false;
-  if (p < npts) {
-    const float4 v = *reinterpret_cast<const float4*>(cloud + (size_t)p * 4);
-    in = ctx_min_d2(v.x, v.y, v.z, pts, nd) < r2;
-  }
+  if (near) in = ctx_min_d2(v.x, v.y, v.z, pts, nd) < r2;
   const unsigned long long bal = __ballot(in);
   const int lane = tid & 63, wave = tid >> 6;
   if (lane == 0) wcnt[wave] = __popcll(bal);

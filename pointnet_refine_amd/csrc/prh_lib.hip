@@ -1028,13 +1028,14 @@ int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B,
 }
 
 // ------------------------------------------------------------------ context builder (row f2)
-struct CtxWS { int* blkcnt; int* blkoff; int* cand; unsigned* keys; };
+struct CtxWS { int* blkcnt; int* blkoff; int* cand; unsigned* keys; float* box; };
 void ctx_carve(Arena& a, CtxWS& w, int npts, int L, int max_cand) {
   const size_t nblk = (size_t)cdiv(npts, 256);
   w.blkcnt = (int*)a.f(nblk * L);
   w.blkoff = (int*)a.f(nblk * L);
   w.cand = (int*)a.f((size_t)L * max_cand);
   w.keys = (unsigned*)a.f((size_t)L * max_cand);
+  w.box = a.f((size_t)L * 6);
 }
 size_t prh_context_workspace_bytes(int npts, int n_lines, int max_candidates) {
   if (npts < 0 || n_lines <= 0 || max_candidates <= 0) return 0;
@@ -1063,13 +1064,15 @@ int prh_context_build(const float* cloud, int npts, const float* dense, int n_de
   if (!a.ok) return fail(PRH_ERR_WORKSPACE, "context_build: workspace too small (%zu bytes)", workspace_bytes);
   const int nblk = cdiv(npts, 256) < 1 ? 1 : cdiv(npts, 256);
   const float r2 = radius * radius;
+  hipLaunchKernelGGL(ctx_bbox_kernel, dim3(n_lines), dim3(64), 0, st, dense, n_dense, radius, w.box);
+  LAUNCH_CHECK();
   hipLaunchKernelGGL((ctx_crop_kernel<false>), dim3(nblk, n_lines), dim3(256), 0, st, cloud, npts, dense, n_dense,
-                     r2, nblk, w.blkcnt, (const int*)nullptr, (int*)nullptr, max_candidates);
+                     (const float*)w.box, r2, nblk, w.blkcnt, (const int*)nullptr, (int*)nullptr, max_candidates);
   LAUNCH_CHECK();
   hipLaunchKernelGGL(ctx_scan_kernel, dim3(n_lines), dim3(256), 0, st, w.blkcnt, nblk, w.blkoff, counts);
   LAUNCH_CHECK();
-  hipLaunchKernelGGL((ctx_crop_kernel<true>), dim3(nblk, n_lines), dim3(256), 0, st, cloud, npts, dense, n_dense, r2,
-                     nblk, w.blkcnt, (const int*)w.blkoff, w.cand, max_candidates);
+  hipLaunchKernelGGL((ctx_crop_kernel<true>), dim3(nblk, n_lines), dim3(256), 0, st, cloud, npts, dense, n_dense,
+                     (const float*)w.box, r2, nblk, w.blkcnt, (const int*)w.blkoff, w.cand, max_candidates);
   LAUNCH_CHECK();
   hipLaunchKernelGGL(ctx_select_kernel, dim3(n_lines), dim3(256), 0, st, cloud, line, m, (const int*)counts,
                      (const int*)w.cand, max_candidates, decay_scale, n_samples, (uint64_t)seed, w.keys, out,
