@@ -77,6 +77,7 @@ def parse():
                          "products, fp32-level error; split = three bf16 planes, 6 products, fp32-level "
                          "error, no range assumption; fp32 = exact fp32 MFMA everywhere; bf16 = reduced "
                          "precision (config 3)")
+    ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of the fused flat-buffer Adam")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16)
     return ap.parse_args()
@@ -151,7 +152,9 @@ def main():
     if launched:
         for p in model.parameters():                 # same start on every rank (DDP does this)
             dist.broadcast(p.data, 0)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    # optimizer=None: the library's flat-buffer Adam (same update as torch.optim.Adam(lr=1e-3),
+    # tests/test_loss_adam_gpu.py), one launch per step; the loss is the fused HIP L1 either way
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3) if args.torch_adam else None
     step = TrainStep(model, opt, decoder_chunk=args.decoder_chunk, world_size=world)
 
     B, N = args.batch, args.points

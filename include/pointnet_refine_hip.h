@@ -179,6 +179,23 @@ int prh_context_build(const float* cloud, int npts, const float* dense, int n_de
                       float* dbg_weights, void* workspace, size_t workspace_bytes, int device,
                       void* stream);
 
+/* Row f3.  Deep-supervision L1 loss with its gradient in one pass (train.py:63-68,
+ * train_dist.py:180-186: (1/L) sum_l nn.L1Loss(pred_l, target)):
+ *   *loss (+)= sum_{l,e} |pred[l,e] - target[e]| / denom      d_pred[l,e] = sign(.) / denom
+ * pred [n_layers, elems], target [elems]; denom = n_layers * elems of the full batch (a
+ * micro-batched caller passes the full-batch denominator and accumulate = 1 from the second
+ * chunk on); d_pred may be NULL.  loss is a device scalar. */
+size_t prh_l1_loss_workspace_bytes(void);
+int prh_l1_loss(const float* pred, const float* target, int n_layers, long elems, double denom,
+                int accumulate, float* loss, float* d_pred, void* workspace, size_t workspace_bytes,
+                int device, void* stream);
+
+/* torch.optim.Adam step (amsgrad off; train.py:40, train_dist.py:150) over flat, 16-byte
+ * aligned fp32 buffers of n elements; step counts from 1. */
+int prh_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, int step, int device,
+                  void* stream);
+
 /* GEMM core selection (environment PRH_GEMM, or prh_set_gemm_mode at run time):
  *   split16 / 3 (default): large GEMMs on the split-fp16 cores - two fp16 planes per fp32 operand
  *            placed by a power-of-two scale from the operand's largest magnitude, three

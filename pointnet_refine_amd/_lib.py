@@ -58,6 +58,7 @@ EXPORTS = [
     "prh_profile_enable", "prh_profile_count", "prh_profile_reset", "prh_profile_read",
     "prh_attn_forward", "prh_attn_backward",
     "prh_context_workspace_bytes", "prh_context_build",
+    "prh_l1_loss_workspace_bytes", "prh_l1_loss", "prh_adam_step",
     "prh_set_gemm_mode", "prh_get_gemm_mode",
     "prh_last_error", "prh_version",
 ]
@@ -125,6 +126,12 @@ def _bind(lib):
     lib.prh_context_build.restype = i
     lib.prh_context_build.argtypes = [vp, i, vp, i, vp, i, i, f, f, i, i, C.c_ulonglong, vp, vp, vp, vp,
                                       C.c_size_t, i, vp]
+    lib.prh_l1_loss_workspace_bytes.restype = C.c_size_t
+    lib.prh_l1_loss_workspace_bytes.argtypes = []
+    lib.prh_l1_loss.restype = i
+    lib.prh_l1_loss.argtypes = [vp, vp, i, lg, C.c_double, i, vp, vp, vp, C.c_size_t, i, vp]
+    lib.prh_adam_step.restype = i
+    lib.prh_adam_step.argtypes = [vp, vp, vp, vp, lg, f, f, f, f, f, i, i, vp]
     lib.prh_set_gemm_mode.restype = i
     lib.prh_set_gemm_mode.argtypes = [i]
     lib.prh_get_gemm_mode.restype = i

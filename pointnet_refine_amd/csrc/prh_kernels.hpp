@@ -378,4 +378,84 @@ __global__ void fill_kernel(float* p, size_t n, float v) {
   if (i < n) p[i] = v;
 }
 
+// ---------------------------------------------------------------------------------------
+// Row f3.  Deep-supervision L1 loss, forward and backward in one pass
+// (train.py:63-68, train_dist.py:180-186: (1/L) sum_l mean|pred_l - target| with nn.L1Loss):
+//   part[block] = sum over the block's elements and all L layers of |pred - target| / denom
+//   d_pred      = sign(pred - target) / denom          (sign(0) = 0, as torch's L1 backward)
+// `denom` is passed in (L * elements of the FULL batch) so a micro-batched caller can add
+// chunk losses.  Two-stage deterministic reduction (l1_final_kernel), no atomics.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l1_deep_kernel(const float* __restrict__ pred,
+                                                      const float* __restrict__ target, int L, long R,
+                                                      float inv_denom, float* __restrict__ d_pred,
+                                                      float* __restrict__ part) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const long stride = (long)gridDim.x * 256;
+  for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < R; r += stride) {
+    const float t = target[r];
+    for (int l = 0; l < L; ++l) {
+      const float d = pred[(size_t)l * R + r] - t;
+      s += fabsf(d);
+      if (d_pred != nullptr) d_pred[(size_t)l * R + r] = d > 0.f ? inv_denom : (d < 0.f ? -inv_denom : 0.f);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void l1_final_kernel(const float* __restrict__ part, int n, float inv_denom,
+                                                       int accumulate, float* __restrict__ loss) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += (double)part[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float v = (float)(red[0] * (double)inv_denom);
+    *loss = accumulate ? *loss + v : v;
+  }
+}
+
+// torch.optim.Adam (no amsgrad, no maximize; train.py:40, train_dist.py:150) over flat buffers:
+//   g' = g + wd*p;  m = b1*m + (1-b1)*g';  v = b2*v + (1-b2)*g'^2
+//   p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long n,
+                                                   float step_size, float b1, float b2, float eps,
+                                                   float wd, float inv_bc2_sqrt) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  if (i + 4 <= n) {
+    float4 P = *reinterpret_cast<float4*>(p + i), M = *reinterpret_cast<float4*>(m + i);
+    float4 V = *reinterpret_cast<float4*>(v + i);
+    const float4 G = *reinterpret_cast<const float4*>(g + i);
+    float* pp = &P.x; float* mm = &M.x; float* vv = &V.x; const float* gg = &G.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gr = fmaf(wd, pp[k], gg[k]);
+      mm[k] = fmaf(b1, mm[k], (1.f - b1) * gr);
+      vv[k] = fmaf(b2, vv[k], (1.f - b2) * gr * gr);
+      pp[k] -= step_size * (mm[k] / (sqrtf(vv[k]) * inv_bc2_sqrt + eps));
+    }
+    *reinterpret_cast<float4*>(p + i) = P;
+    *reinterpret_cast<float4*>(m + i) = M;
+    *reinterpret_cast<float4*>(v + i) = V;
+  } else {
+    for (long j = i; j < n; ++j) {
+      const float gr = fmaf(wd, p[j], g[j]);
+      m[j] = fmaf(b1, m[j], (1.f - b1) * gr);
+      v[j] = fmaf(b2, v[j], (1.f - b2) * gr * gr);
+      p[j] -= step_size * (m[j] / (sqrtf(v[j]) * inv_bc2_sqrt + eps));
+    }
+  }
+}
+
 }  // namespace prh

@@ -1027,6 +1027,46 @@ int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B,
   return PRH_OK;
 }
 
+// ------------------------------------------------------------------ loss + optimiser (row f3)
+constexpr int L1_BLOCKS = 1024;
+size_t prh_l1_loss_workspace_bytes(void) { return (size_t)L1_BLOCKS * sizeof(float) + 256; }
+int prh_l1_loss(const float* pred, const float* target, int n_layers, long elems, double denom,
+                int accumulate, float* loss, float* d_pred, void* workspace, size_t workspace_bytes,
+                int device, void* stream) {
+  if (!pred || !target || !loss || n_layers <= 0 || elems <= 0 || !(denom > 0.0))
+    return fail(PRH_ERR_ARG, "l1_loss: bad argument");
+  Arena a(workspace, workspace_bytes);
+  float* part = a.f(L1_BLOCKS);
+  if (!a.ok) return fail(PRH_ERR_WORKSPACE, "l1_loss: workspace too small (%zu bytes)", workspace_bytes);
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  long blocks = cdiv(elems, 256L);
+  blocks = blocks > L1_BLOCKS ? L1_BLOCKS : blocks;
+  const float inv = (float)(1.0 / denom);
+  hipLaunchKernelGGL(l1_deep_kernel, dim3((unsigned)blocks), dim3(256), 0, st, pred, target, n_layers, elems, inv,
+                     d_pred, part);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(256), 0, st, (const float*)part, (int)blocks, inv, accumulate, loss);
+  LAUNCH_CHECK();
+  return PRH_OK;
+}
+int prh_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, int step, int device,
+                  void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || n < 0 || step < 1)
+    return fail(PRH_ERR_ARG, "adam_step: bad argument (step counts from 1)");
+  if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15)
+    return fail(PRH_ERR_ARG, "adam_step: buffers must be 16-byte aligned");
+  if (n == 0) return PRH_OK;
+  HIP_TRY(hipSetDevice(device));
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)cdiv(cdiv(n, 4L), 256L)), dim3(256), 0, (hipStream_t)stream, param,
+                     grad, exp_avg, exp_avg_sq, n, (float)(lr / bc1), beta1, beta2, eps, weight_decay,
+                     (float)(1.0 / sqrt(bc2)));
+  LAUNCH_CHECK();
+  return PRH_OK;
+}
+
 // ------------------------------------------------------------------ context builder (row f2)
 struct CtxWS { int* blkcnt; int* blkoff; int* cand; unsigned* keys; float* box; };
 void ctx_carve(Arena& a, CtxWS& w, int npts, int L, int max_cand) {

@@ -472,3 +472,37 @@ def attention_keep_mask(B, H, M, N, dropout_p, seed, device="cpu"):
     x = (x * 0xC2B2AE35) & m32
     x = x ^ (x >> 16)
     return x >= int(float(dropout_p) * 4294967296.0)
+
+
+class DeepSupervisionL1Fn(torch.autograd.Function):
+    """sum_{l,e} |pred[l,e] - target[e]| / denom with its gradient produced in the same pass
+    (row f3; train.py:63-68, train_dist.py:180-186).  pred (L, ...), target (...)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, denom):
+        _req_gpu_f32(pred, "pred")
+        _req_gpu_f32(target, "target")
+        if pred.shape[1:] != target.shape:
+            raise RuntimeError(f"deep_supervision_l1: pred {tuple(pred.shape)} vs target {tuple(target.shape)}")
+        pred, target = pred.contiguous(), target.contiguous()
+        dev = pred.device
+        need = ctx.needs_input_grad[0]
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        d_pred = torch.empty_like(pred) if need else None
+        nb = L.lib().prh_l1_loss_workspace_bytes()
+        ws = _ws(dev, nb)
+        L.check(L.lib().prh_l1_loss(_p(pred), _p(target), pred.shape[0], target.numel(), float(denom), 0, _p(loss),
+                                    _p(d_pred), _p(ws), ws.numel(), dev.index, _stream(dev)), "prh_l1_loss")
+        if need:
+            ctx.save_for_backward(d_pred)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (d_pred,) = ctx.saved_tensors
+        return d_pred * g, None, None
+
+
+def deep_supervision_l1(pred, target, denom=None):
+    """(1/L) sum_l mean|pred_l - target| on the HIP path; denom defaults to pred.numel()."""
+    return DeepSupervisionL1Fn.apply(pred, target, float(pred.numel() if denom is None else denom))

@@ -23,6 +23,8 @@ from typing import Optional
 import torch
 import torch.distributed as dist
 
+from . import ops
+
 
 class FlatGrads:
     """All parameter gradients as views into one buffer; one collective per step."""
@@ -80,18 +82,66 @@ class FlatBuffers:
                 b.copy_(fi[i])
 
 
-def deep_supervision_l1(out, target):
-    """(1/L) sum_l mean|pred_l - target|  (train.py:63-68, train_dist.py:180-186)."""
-    return (out - target.unsqueeze(0)).abs().mean()
+def deep_supervision_l1(out, target, denom=None):
+    """sum_l sum |pred_l - target| / denom, denom = out.numel() by default: (1/L) sum_l
+    nn.L1Loss(pred_l, target) of train.py:63-68 / train_dist.py:180-186, as one HIP pass that
+    also produces the gradient (row f3).  GPU tensors only."""
+    return ops.deep_supervision_l1(out, target, denom)
+
+
+class FlatAdam:
+    """torch.optim.Adam semantics (lr 1e-3, betas (0.9, 0.999), eps 1e-8, no amsgrad: the
+    reference's optimiser, train.py:40 / train_dist.py:150) as ONE HIP launch per step over flat
+    buffers (row f3): the parameters become views into one fp32 buffer laid out like the
+    FlatGrads gradient buffer, with flat first/second-moment buffers next to it.  Duck-types the
+    optimizer calls the reference's loops make (step, zero_grad, param_groups[0]['lr'])."""
+
+    def __init__(self, grads: "FlatGrads", lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.grads = grads
+        self.param_groups = [{"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": weight_decay,
+                              "params": grads.params}]
+        flat = torch.empty_like(grads.flat)
+        off = 0
+        with torch.no_grad():
+            for p in grads.params:
+                n = p.numel()
+                flat[off:off + n].copy_(p.detach().reshape(-1))
+                p.data = flat[off:off + n].view_as(p)          # parameters now live in the flat buffer
+                off += n
+        self.flat = flat
+        self.exp_avg = torch.zeros_like(flat)
+        self.exp_avg_sq = torch.zeros_like(flat)
+        self.steps = 0
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.grads.zero()
+
+    @torch.no_grad()
+    def step(self):
+        import ctypes as C
+        from . import _lib as L
+        self.steps += 1
+        g = self.param_groups[0]
+        dev = self.flat.device
+        p = lambda t: C.c_void_p(t.data_ptr())
+        L.check(L.lib().prh_adam_step(p(self.flat), p(self.grads.flat), p(self.exp_avg), p(self.exp_avg_sq),
+                                      self.flat.numel(), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
+                                      float(g["eps"]), float(g["weight_decay"]), self.steps, dev.index,
+                                      C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "prh_adam_step")
 
 
 class TrainStep:
-    def __init__(self, model, optimizer, decoder_chunk: Optional[int] = None, world_size: int = 1,
-                 group=None, broadcast_buffers: bool = True):
-        self.model, self.opt = model, optimizer
+    def __init__(self, model, optimizer=None, decoder_chunk: Optional[int] = None, world_size: int = 1,
+                 group=None, broadcast_buffers: bool = True, lr: float = 1e-3, loss_fn=None):
+        """optimizer = None: the fused flat-buffer Adam (FlatAdam, the reference's Adam(lr=1e-3));
+        any torch optimizer over model.parameters() also works.  loss_fn(out, target, denom):
+        defaults to the HIP deep-supervision L1 (the reference's loss)."""
+        self.model = model
+        self.loss_fn = loss_fn if loss_fn is not None else deep_supervision_l1
         self.chunk = decoder_chunk
         self.world, self.group = world_size, group
         self.grads = FlatGrads(model.parameters())
+        self.opt = optimizer if optimizer is not None else FlatAdam(self.grads, lr=lr)
         distributed = dist.is_available() and dist.is_initialized()
         self.bufs = FlatBuffers(model) if (distributed and broadcast_buffers) else None
 
@@ -100,7 +150,7 @@ class TrainStep:
         B = context.shape[0]
         if self.chunk is None or self.chunk >= B or not hasattr(m, "decode"):
             out = m(context, noisy_line)
-            loss = deep_supervision_l1(out, target)
+            loss = self.loss_fn(out, target, float(out.numel()))
             loss.backward()
             return loss.detach()
         # encoder side at full batch (BatchNorm statistics span the whole per-rank batch)
@@ -116,7 +166,7 @@ class TrainStep:
             mem_c = mem_d[s:e].requires_grad_()
             tgt_c = tgt_d[s:e].requires_grad_()
             out = m.decode(context[s:e], noisy_line[s:e], mem_c, tgt_c)
-            loss_c = (out - target[s:e].unsqueeze(0)).abs().sum() / denom
+            loss_c = self.loss_fn(out, target[s:e], denom)
             loss_c.backward()
             d_memory[s:e] = mem_c.grad
             d_tgt0[s:e] = tgt_c.grad

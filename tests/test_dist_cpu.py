@@ -29,6 +29,12 @@ class Tiny(torch.nn.Module):
         return torch.stack([off + noisy_line * 0.1 * l for l in range(6)])
 
 
+def _torch_l1(out, target, denom=None):
+    """The reference's loss in torch ops for the CPU stand-in models of this file (the product's
+    default loss is the HIP kernel, which - like the model - has no CPU path)."""
+    return (out - target.unsqueeze(0)).abs().sum() / (out.numel() if denom is None else denom)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -42,7 +48,7 @@ def _worker(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from pointnet_refine_amd.train_step import TrainStep, deep_supervision_l1
+    from pointnet_refine_amd.train_step import TrainStep
     torch.manual_seed(0)
     model = Tiny().train()
     if rank == 1:                       # rank 1 starts with different BN buffers: must be overwritten
@@ -54,12 +60,12 @@ def _worker(rank, world, port, out):
     line = torch.randn(6, 32, 3, generator=g)
     tgt = torch.randn(6, 32, 3, generator=g)
     opt = torch.optim.SGD(model.parameters(), lr=0.1)
-    step = TrainStep(model, opt, decoder_chunk=None, world_size=world)
+    step = TrainStep(model, opt, decoder_chunk=None, world_size=world, loss_fn=_torch_l1)
     loss = step(ctx, line, tgt)
     # expected: mean over ranks of the per-rank gradients of the pre-step weights
     if rank == 1:
         ref.bn.running_mean.sub_(5.0)
-    deep_supervision_l1(ref(ctx, line), tgt).backward()
+    _torch_l1(ref(ctx, line), tgt).backward()
     flat = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
     dist.all_reduce(flat)
     flat /= world
@@ -128,8 +134,8 @@ def test_chunked_decoder_matches_monolithic_step():
     a, b = Split().train(), Split().train()
     b.load_state_dict(a.state_dict())
     ctx, line, tgt = torch.randn(8, 10, 4), torch.randn(8, 32, 3), torch.randn(8, 32, 3)
-    sa = TrainStep(a, torch.optim.SGD(a.parameters(), lr=0.0), decoder_chunk=None)
-    sb = TrainStep(b, torch.optim.SGD(b.parameters(), lr=0.0), decoder_chunk=3)
+    sa = TrainStep(a, torch.optim.SGD(a.parameters(), lr=0.0), decoder_chunk=None, loss_fn=_torch_l1)
+    sb = TrainStep(b, torch.optim.SGD(b.parameters(), lr=0.0), decoder_chunk=3, loss_fn=_torch_l1)
     la, lb = sa(ctx, line, tgt), sb(ctx, line, tgt)
     assert abs(float(la) - float(lb)) < 1e-6
     assert float((sa.grads.flat - sb.grads.flat).abs().max()) < 1e-6
