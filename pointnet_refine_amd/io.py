@@ -1,0 +1,96 @@
+"""On-disk formats and the whole-scene driver - host code.
+
+  load_pcd_data      PCD reader with the reference's behaviour (src/dataset.py:31-76): ASCII via
+                     numpy, binary as 16-byte xyzi-f32 or 14-byte xyz-f32 + u2-intensity records
+                     chosen by payload size, an empty (0,4) array (plus a message) for anything
+                     else - the reference's callers rely on "never raises"
+  load_scene_items   the scene JSON schema: items[].position / noisy_candidates[][] /
+                     context_lines[][] of {x,y,z} (src/dataset.py:172-187,
+                     tools/generate_train_data.py:184-209)
+  refine_scene       inference_whole_scene.py:94-146 for all lines of a scene at once: contexts
+                     from the GPU builder (context.py), batched eval forward, refined line =
+                     resampled noisy line + last-layer offset
+"""
+import json
+
+import numpy as np
+import torch
+
+from .context import build_contexts
+
+_XYZI_F32 = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("intensity", "<f4")])
+_XYZ_F32_I_U2 = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("intensity", "<u2")])
+
+
+def load_pcd_data(pcd_path):
+    """(P,4) float32 xyz + intensity (reference: src/dataset.py:31-76)."""
+    try:
+        with open(pcd_path, "rb") as f:
+            header = []
+            while True:
+                raw = f.readline()
+                if not raw:
+                    raise ValueError("no DATA line in the PCD header")
+                line = raw.strip()
+                header.append(line)
+                if line.startswith(b"DATA"):
+                    break
+            kind = header[-1].split()[1]
+            if kind == b"ascii":
+                return np.loadtxt(pcd_path, skiprows=len(header), dtype=np.float32)
+            payload = f.read()
+        n_points = int([h for h in header if h.startswith(b"POINTS")][0].split()[1])
+        for dt in (_XYZI_F32, _XYZ_F32_I_U2):
+            if len(payload) == n_points * dt.itemsize:
+                rec = np.frombuffer(payload, dtype=dt)
+                return np.column_stack((rec["x"], rec["y"], rec["z"], rec["intensity"].astype(np.float32)))
+        print(f"Unknown binary format for {pcd_path}, bytes={len(payload)}, points={n_points}")
+        return np.zeros((0, 4), dtype=np.float32)
+    except Exception as e:                       # the reference reports and carries on
+        print(f"Error loading {pcd_path}: {e}")
+        return np.zeros((0, 4), dtype=np.float32)
+
+
+def _xyz(points):
+    return np.array([[p["x"], p["y"], p["z"]] for p in points], dtype=np.float64).reshape(-1, 3)
+
+
+def load_scene_items(json_path):
+    """List of dicts with numpy polylines: 'position' (ground truth, may be absent),
+    'noisy_candidates' (list), 'context_lines' (list, empty lines dropped)."""
+    with open(json_path, "r") as f:
+        data = json.load(f)
+    items = []
+    for item in data.get("items", []):
+        items.append({
+            "position": _xyz(item["position"]) if "position" in item else None,
+            "noisy_candidates": [_xyz(c) for c in item.get("noisy_candidates", [])],
+            "context_lines": [_xyz(l) for l in item.get("context_lines", []) if len(l) > 0],
+        })
+    return items
+
+
+@torch.no_grad()
+def refine_scene(model, pcd_points, raw_lines, num_line_points=32, num_context_points=1024,
+                 crop_radius=0.3, decay_scale=2.0, batch_lines=512, seed=0):
+    """Refine every polyline of a scene (inference_whole_scene.py:94-146, NUM_CONTEXT_POINTS 1024,
+    CROP_RADIUS 0.3).  pcd_points (P,4) numpy or CUDA tensor; raw_lines list of (n_i,3).
+    Returns (refined (L,M,3), noisy_resampled (L,M,3)) numpy arrays in scene coordinates."""
+    dev = next(model.parameters()).device
+    cloud = pcd_points if torch.is_tensor(pcd_points) else torch.from_numpy(np.ascontiguousarray(pcd_points, dtype=np.float32))
+    cloud = cloud.to(dev, torch.float32)
+    if len(raw_lines) == 0:
+        return np.zeros((0, num_line_points, 3)), np.zeros((0, num_line_points, 3))
+    was_training = model.training
+    model.eval()
+    try:
+        ctx, noisy_c, centres, _ = build_contexts(cloud, raw_lines, num_line_points, num_context_points,
+                                                  crop_radius, decay_scale, seed)
+        outs = []
+        for s in range(0, ctx.shape[0], batch_lines):
+            outs.append(model(ctx[s:s + batch_lines], noisy_c[s:s + batch_lines])[-1])   # last layer, :139-141
+        offset = torch.cat(outs)
+        noisy = noisy_c + centres[:, None, :]
+        return (noisy + offset).cpu().numpy(), noisy.cpu().numpy()                         # :146
+    finally:
+        model.train(was_training)

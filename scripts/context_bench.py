@@ -45,6 +45,19 @@ print(f"GPU: {L} lines x {P} points, N={N}: {ms:.2f} ms = {L / ms * 1e3:.0f} lin
       f"{evals / ms / 1e6:.1f} G brute-force-equivalent point-to-sample distance evaluations/s "
       f"(~{evals * 8 / ms / 1e9:.1f} TFLOP/s fp32 VALU of 157.3; bounding boxes skip most of them); host resampling {t_host * 1e3:.0f} ms; "
       f"mean points in tube {float(counts.float().mean()):.0f}")
+# whole-scene refinement (config 5 shape): contexts + batched eval forward, random-init weights
+from pointnet_refine_amd.io import refine_scene
+from pointnet_refine_amd.model import LineRefineNet
+torch.manual_seed(0)
+model = LineRefineNet().to(dev).eval()
+refine_scene(model, ct, lines[:512], batch_lines=512)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+refined, _ = refine_scene(model, ct, lines, batch_lines=512, seed=1)
+torch.cuda.synchronize()
+t_scene = time.perf_counter() - t0
+print(f"refine_scene: {L} lines end to end (host resampling + contexts + fp32 eval forward in batches of 512 + "
+      f"copy back) {t_scene * 1e3:.0f} ms = {L / t_scene:.0f} lines/s")
 nb = 16
 t0 = time.perf_counter()
 for i in range(nb):

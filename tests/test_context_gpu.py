@@ -113,3 +113,30 @@ def test_whole_scene_size_and_error_behaviour():
         assert int(counts[i]) == int(O.crop_mask(cloud, O.arc_resample(lines[i], 200), 0.3).sum())
     with pytest.raises(RuntimeError):
         build_contexts(ct.cpu(), lines[:2])
+
+
+def test_refine_scene_driver(tmp_path):
+    """inference_whole_scene.py:94-146 for a whole scene at once: refined = resampled noisy line +
+    last-layer offset of the model on the contexts the builder produced (deterministic per seed)."""
+    from pointnet_refine_amd.context import build_contexts
+    from pointnet_refine_amd.io import refine_scene
+    from pointnet_refine_amd.model import LineRefineNet
+    from oracle import procedural as P
+    rng = np.random.default_rng(4)
+    lines = [np.stack([np.sort(rng.uniform(-20, 20, 5)), np.full(5, 2.0 * i), np.zeros(5)], 1) for i in range(5)]
+    xyz = np.stack([rng.uniform(-22, 22, 20000), rng.uniform(-2, 10, 20000), rng.normal(0, 0.05, 20000)], 1)
+    cloud = np.column_stack([xyz, rng.uniform(0, 60, 20000)]).astype(np.float32)
+    m = LineRefineNet()
+    m.load_state_dict(P.linerefine_state_dict(0))
+    m = m.cuda().train()
+    refined, noisy = refine_scene(m, cloud, lines, num_context_points=256, crop_radius=0.5, batch_lines=2, seed=3)
+    assert m.training                                           # mode restored
+    assert refined.shape == (5, 32, 3) and noisy.shape == (5, 32, 3)
+    for i in range(5):
+        assert np.allclose(noisy[i], O.arc_resample(lines[i], 32), atol=1e-5)
+    ctx, noisy_c, centres, _ = build_contexts(torch.from_numpy(cloud).cuda(), lines, 32, 256, 0.5, 2.0, seed=3)
+    with torch.no_grad():
+        off = m.eval()(ctx, noisy_c)[-1]
+    assert np.allclose(refined - noisy, off.cpu().numpy(), atol=2e-5)    # batching does not change eval results
+    empty_r, empty_n = refine_scene(m, cloud, [])
+    assert empty_r.shape == (0, 32, 3)
