@@ -94,3 +94,57 @@ def refine_scene(model, pcd_points, raw_lines, num_line_points=32, num_context_p
         return (noisy + offset).cpu().numpy(), noisy.cpu().numpy()                         # :146
     finally:
         model.train(was_training)
+
+
+class SceneSampleStream:
+    """Training samples straight from scene files, one batch per scene, built on the GPU.
+
+    The reference's ``LaneRefineDataset`` (src/dataset.py:132-253) builds ONE sample per
+    ``__getitem__`` in DataLoader workers: JSON parse, KDTree crop of the whole cloud, numpy
+    sampling.  Here a scene's cloud goes to the device once and the contexts of ALL its samples
+    (every noisy candidate of every item, :152-166) come from one ``prh_context_build`` call.
+    Same constructor arguments and the same per-sample tensors: ``context (N,4)`` centred on the
+    noisy line's mean with raw intensity, ``noisy_line (M,3)`` centred, ``target_offset (M,3)`` =
+    resampled ground truth - resampled noisy line (:206-207,241).  Iterating yields dicts of
+    CUDA tensors with a leading sample dimension; ``len()`` is the number of samples."""
+
+    def __init__(self, data_root, num_line_points=32, num_context_points=2048, crop_radius=4.0,
+                 decay_scale=2.0, split="train", device="cuda", seed=0):
+        import os
+        self.num_line_points, self.num_context_points = num_line_points, num_context_points
+        self.crop_radius, self.decay_scale = crop_radius, decay_scale
+        self.device, self.seed, self.split = torch.device(device), seed, split
+        self.scenes = []                       # (pcd_path, json_path, [(item_idx, noise_idx), ...])
+        for name in sorted(f for f in os.listdir(data_root) if f.endswith(".json")):
+            json_path = os.path.join(data_root, name)
+            pcd_path = json_path.replace(".json", ".pcd")
+            if not os.path.exists(pcd_path):
+                continue                                             # :149-150
+            with open(json_path, "r") as f:
+                data = json.load(f)
+            pairs = [(i, k) for i, item in enumerate(data.get("items", []))
+                     if "noisy_candidates" in item and "position" in item               # :156-157
+                     for k in range(len(item["noisy_candidates"]))]
+            if pairs:
+                self.scenes.append((pcd_path, json_path, pairs))
+        self.epoch = 0
+
+    def __len__(self):
+        return sum(len(s[2]) for s in self.scenes)
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def __iter__(self):
+        from .context import resample_polyline
+        for si, (pcd_path, json_path, pairs) in enumerate(self.scenes):
+            cloud = torch.from_numpy(load_pcd_data(pcd_path)).to(self.device, torch.float32)
+            items = load_scene_items(json_path)
+            raw_noisy = [items[i]["noisy_candidates"][k] for i, k in pairs]
+            gt = np.stack([resample_polyline(items[i]["position"], self.num_line_points) for i, _ in pairs])
+            ctx, noisy_c, centres, counts = build_contexts(
+                cloud.reshape(-1, 4), raw_noisy, self.num_line_points, self.num_context_points, self.crop_radius,
+                self.decay_scale, seed=(self.seed * 1000003 + self.epoch) * 65537 + si)
+            gt_c = torch.from_numpy(gt).to(self.device, torch.float32) - centres[:, None, :]
+            yield {"context": ctx, "noisy_line": noisy_c, "target_offset": gt_c - noisy_c,
+                   "points_in_tube": counts, "scene": pcd_path}

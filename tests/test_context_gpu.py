@@ -140,3 +140,40 @@ def test_refine_scene_driver(tmp_path):
     assert np.allclose(refined - noisy, off.cpu().numpy(), atol=2e-5)    # batching does not change eval results
     empty_r, empty_n = refine_scene(m, cloud, [])
     assert empty_r.shape == (0, 32, 3)
+
+
+def test_scene_sample_stream(tmp_path):
+    """Scene files -> per-sample tensors with the reference's sample contract (src/dataset.py:241-253)."""
+    import json
+    from pointnet_refine_amd.io import SceneSampleStream
+    rng = np.random.default_rng(9)
+    p = lambda a: [{"x": float(x), "y": float(y), "z": float(z)} for x, y, z in a]
+    n_samples = 0
+    for s in range(2):
+        P_ = 5000
+        xyz = np.stack([rng.uniform(-25, 25, P_), rng.uniform(-3, 3, P_), rng.normal(0, 0.05, P_)], 1).astype(np.float32)
+        inten = rng.uniform(0, 80, P_).astype(np.float32)
+        rec = np.zeros(P_, dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("intensity", "<f4")])
+        rec["x"], rec["y"], rec["z"], rec["intensity"] = xyz[:, 0], xyz[:, 1], xyz[:, 2], inten
+        hdr = (f"VERSION 0.7\nFIELDS x y z intensity\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\nWIDTH {P_}\n"
+               f"HEIGHT 1\nPOINTS {P_}\nDATA binary\n").encode()
+        (tmp_path / f"s{s}.pcd").write_bytes(hdr + rec.tobytes())
+        items = []
+        for i in range(3):
+            gt = np.stack([np.linspace(-20, 20, 6), np.full(6, i - 1.0), np.zeros(6)], 1)
+            cands = [gt + rng.normal(0, 0.1, gt.shape) for _ in range(2)]
+            n_samples += 2
+            items.append({"position": p(gt), "noisy_candidates": [p(c) for c in cands], "context_lines": []})
+        items.append({"noisy_candidates": [p(gt)]})                        # no ground truth: skipped (:156-157)
+        (tmp_path / f"s{s}.json").write_text(json.dumps({"items": items}))
+    (tmp_path / "orphan.json").write_text(json.dumps({"items": []}))      # no .pcd beside it: skipped (:149-150)
+    ds = SceneSampleStream(str(tmp_path), num_context_points=128, crop_radius=0.5)
+    assert len(ds) == n_samples == 12
+    seen = 0
+    for batch in ds:
+        c, nl, t = batch["context"], batch["noisy_line"], batch["target_offset"]
+        assert c.shape == (6, 128, 4) and nl.shape == (6, 32, 3) and t.shape == (6, 32, 3)
+        assert c.is_cuda and float(nl.mean(dim=1).abs().max()) < 1e-4       # centred on the noisy line's mean
+        assert float(t.abs().max()) < 1.0 and int(batch["points_in_tube"].min()) > 128
+        seen += c.shape[0]
+    assert seen == 12
