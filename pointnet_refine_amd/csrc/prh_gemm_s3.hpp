@@ -400,11 +400,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
   // W planes: pre-split, pre-swizzled image -> straight global->LDS DMA (no registers, no
   // ds_write), issued from inline asm and waited for by the counted vmcnt that ends the k-tile.
   auto dma_w = [&](int kt, int stage) {
-#ifdef PRH_EXP_HOT_W
-    const char* q = wsrc + (size_t)(kt & 1) * S3_OPER;
-#else
     const char* q = wsrc + (size_t)(kt < KT ? kt : KT - 1) * S3_OPER;   // tail: harmless re-copy
-#endif
 #pragma unroll
     for (int pl = 0; pl < NPL; ++pl) glds16(q + pl * S3_PLANE, wdst + stage * S3_STAGE + pl * S3_PLANE);
   };
@@ -435,11 +431,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_s3_kernel(const NTParams p,
     }
   }
   auto load_tile = [&](int kt, float4 (&r)[2], float4 (&r2)[2]) {
-#ifdef PRH_EXP_HOT_A
-    const int so = (kt & 1) * (S3_BK * 4);
-#else
     const int so = kt * (S3_BK * 4);
-#endif
     if (PRO == PRO_GATE1) return;     // operand is generated from gi[], nothing to load
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
