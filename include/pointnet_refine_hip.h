@@ -83,6 +83,11 @@ typedef struct {
   float* bn_mean;    /* [cat+out_dim] */
   float* bn_rstd;    /* [cat+out_dim] */
   int32_t* argmax;   /* [B, out_dim]  first arg-max point of the max-pool; NULL = skip */
+  float* op_amax;    /* [8] or NULL.  Training with the split-fp16 cores: the forward writes the
+                      * largest activation of conv1..5 (and their maximum) here, taken from the
+                      * statistics epilogues, and the backward reads them as operand scales of
+                      * its wgrads instead of re-measuring.  Pass the same buffer to both calls
+                      * (and keep the GEMM mode unchanged in between), or NULL to both. */
 } prh_encoder_saved;
 
 /* Bytes of scratch the encoder entry points need for P = B*N points

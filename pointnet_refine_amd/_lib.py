@@ -46,7 +46,7 @@ class EncoderGrads(C.Structure):
 class EncoderSaved(C.Structure):
     _fields_ = [("z_cat", C.c_void_p), ("z_fus", C.c_void_p), ("gate", C.c_void_p),
                 ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p), ("bn_mean", C.c_void_p),
-                ("bn_rstd", C.c_void_p), ("argmax", C.c_void_p)]
+                ("bn_rstd", C.c_void_p), ("argmax", C.c_void_p), ("op_amax", C.c_void_p)]
 
 
 EXPORTS = [

@@ -54,6 +54,8 @@ struct NTParams {
   const float* es; const float* et;  // epilogue per-column scale/shift
   float* C2;       long ldc2;    // EPI_GATE second output
   float* ws_a; float* ws_b;      // stats partials [2*row_tiles][N]
+  float* ws_c; float* ws_d;      // EPI_BIAS_STATS: per-column max / min of the outputs per row block
+                                 //   (null: not produced) - the exact maximum of relu(bn(z)) follows
   int flags;
   int tiles_n;
   char* wprep;                   // scratch for the split weight image (null: fp32 MFMA core)
@@ -159,6 +161,20 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[MT][NT], const NTParam
         if (half == 0 && cok) {
           p.ws_a[(size_t)rb * p.N + col] = s;
           p.ws_b[(size_t)rb * p.N + col] = m2;
+        }
+        if (p.ws_c != nullptr) {
+          float mx = -3.0e38f, mn = 3.0e38f;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if (mt * 32 + crow(r, half) < mrows) { mx = fmaxf(mx, acc[mt][nt][r]); mn = fminf(mn, acc[mt][nt][r]); }
+          mx = fmaxf(mx, __shfl_xor(mx, 32));
+          mn = fminf(mn, __shfl_xor(mn, 32));
+          if (half == 0 && cok) {
+            p.ws_c[(size_t)rb * p.N + col] = mx;
+            p.ws_d[(size_t)rb * p.N + col] = mn;
+          }
         }
       }
     } else if (EPI == EPI_GATE) {
@@ -278,6 +294,22 @@ __device__ __forceinline__ void epi_col_stats(const f32x16 (&acc)[MT][2], const 
       p.ws_a[(size_t)rb * p.N + col] = s;
       p.ws_b[(size_t)rb * p.N + col] = m2;
     }
+    if (p.ws_c != nullptr) {
+      float mx = -3.0e38f, mn = 3.0e38f;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (mt * 32 + crow(r, half) < mrows) {
+            mx = fmaxf(mx, acc[mt][nt][r] + bias); mn = fminf(mn, acc[mt][nt][r] + bias);
+          }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      mn = fminf(mn, __shfl_xor(mn, 32));
+      if (half == 0 && cok) {
+        p.ws_c[(size_t)rb * p.N + col] = mx;
+        p.ws_d[(size_t)rb * p.N + col] = mn;
+      }
+    }
   }
 }
 template <int MB>
@@ -312,6 +344,24 @@ __device__ __forceinline__ void epi_col_stats(const f32x4 (&acc)[MB][4], const N
     if (q == 0 && cok) {
       p.ws_a[(size_t)rb * p.N + col] = s;
       p.ws_b[(size_t)rb * p.N + col] = m2;
+    }
+    if (p.ws_c != nullptr) {
+      float mx = -3.0e38f, mn = 3.0e38f;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (mb * 16 + q * 4 + r < mrows) {
+            mx = fmaxf(mx, acc[mb][nb][r] + bias); mn = fminf(mn, acc[mb][nb][r] + bias);
+          }
+      mx = fmaxf(fmaxf(mx, __shfl_xor(mx, 16)), 0.f - 3.0e38f);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      mn = fminf(mn, __shfl_xor(mn, 16));
+      mn = fminf(mn, __shfl_xor(mn, 32));
+      if (q == 0 && cok) {
+        p.ws_c[(size_t)rb * p.N + col] = mx;
+        p.ws_d[(size_t)rb * p.N + col] = mn;
+      }
     }
   }
 }

@@ -107,6 +107,46 @@ __global__ void bn_fwd_finalize_kernel(const double* __restrict__ sl, int P, int
   }
 }
 
+// Largest value of relu(z*scale + shift) from the per-row-block column maxima / minima the
+// statistics epilogue recorded (the activation is convex in z, so its maximum over a set of
+// rows sits at that set's largest or smallest z): the exact operand maximum of the next GEMM,
+// without a pass over the activations.  grid (ceil(N/32), BN_SLICES); part[] -> absmax_final.
+__global__ __launch_bounds__(256) void act_amax_kernel(const float* __restrict__ ws_c,
+                                                       const float* __restrict__ ws_d, int R, long ld, int N,
+                                                       const float* __restrict__ scale,
+                                                       const float* __restrict__ shift,
+                                                       float* __restrict__ part) {
+  __shared__ float red[256];
+  const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + c, sl = blockIdx.y;
+  const int per = (R + BN_SLICES - 1) / BN_SLICES;
+  const int r0 = sl * per, r1 = (r0 + per < R) ? r0 + per : R;
+  float mx = -3.0e38f, mn = 3.0e38f;
+  if (col < N)
+    for (int i = r0 + g; i < r1; i += 8) {
+      mx = fmaxf(mx, ws_c[(size_t)i * ld + col]);
+      mn = fminf(mn, ws_d[(size_t)i * ld + col]);
+    }
+  float a = 0.f;
+  if (col < N && mx >= mn) {
+    const float sc = scale[col], sh = shift[col];
+    a = fmaxf(fmaxf(fmaf(mx, sc, sh), fmaf(mn, sc, sh)), 0.f);
+  }
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.y * gridDim.x + blockIdx.x] = red[0];
+}
+// out[0] = max(v[0..n))   (operand maximum of the fusion conv = maximum over the five blocks)
+__global__ void max_of_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
+  float m = 0.f;
+  for (int i = 0; i < n; ++i) m = fmaxf(m, v[i]);
+  *out = m;
+}
+
 // eval-mode coefficients from running statistics
 __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm,
                                       const float* rv, float eps, int N, float* mean_out,

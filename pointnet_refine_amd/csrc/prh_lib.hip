@@ -457,6 +457,9 @@ struct StackWS {
   float* w0pad = nullptr;   // [cout0, cin0p]
   float* ws_a = nullptr;    // stats partials [stat_tiles_max][maxc]
   float* ws_b = nullptr;
+  float* ws_c = nullptr;    // forward: per-column max / min of z per row block [stat_tiles_max][max cout]
+  float* ws_d = nullptr;
+  float* apart = nullptr;   // per-block maxima of act_amax_kernel [ABSMAX_MAX_BLOCKS]
   double* stat2 = nullptr;  // stage-1 slice records [BN_SLICES][3][maxc]
   char* wprep = nullptr;    // split-bf16 weight image of the layer being run
 };
@@ -476,14 +479,24 @@ bool stack_ws_carve(Arena& a, StackWS& w, int P, const prh_bn_layer* ly, int L, 
   if (d.cin0p != d.cin0) { w.xpad = a.f((size_t)P * d.cin0p); w.w0pad = a.f((size_t)ly[0].cout * d.cin0p); }
   w.ws_a = a.f((size_t)stat_tiles_max(P) * maxc);
   w.ws_b = a.f((size_t)stat_tiles_max(P) * maxc);
+  {
+    int mco = extra_n;
+    for (int l = 0; l < L; ++l) mco = ly[l].cout > mco ? ly[l].cout : mco;
+    w.ws_c = a.f((size_t)stat_tiles_max(P) * mco);
+    w.ws_d = a.f((size_t)stat_tiles_max(P) * mco);
+    w.apart = a.f(ABSMAX_MAX_BLOCKS);
+  }
   w.stat2 = (double*)a.f((size_t)BN_SLICES * 3 * maxc * 2);
   w.wprep = (char*)a.f(wprep_floats(ly, L, extra_n, extra_k));
   return a.ok;
 }
 
+// amax_slot (training, optional): receives the largest value of relu(BN(z)) from the column
+// maxima / minima in ws_c / ws_d - the operand maximum of the GEMMs that consume this layer
 int bn_coeffs(const prh_bn_layer& ly, int P, int training, float momentum, float eps,
               const float* ws_a, const float* ws_b, double* stat2, StatInfo si, float* mean,
-              float* rstd, float* scale, float* shift, hipStream_t st) {
+              float* rstd, float* scale, float* shift, hipStream_t st, const float* ws_c = nullptr,
+              const float* ws_d = nullptr, float* apart = nullptr, float* amax_slot = nullptr) {
   if (training) {
     hipLaunchKernelGGL(bn_stage1_kernel, dim3(cdiv(ly.cout, 32), BN_SLICES), dim3(256), 0, st, ws_a,
                        ws_b, si.count, (long)ly.cout, ly.cout, si.rows, P, 1, stat2);
@@ -491,6 +504,14 @@ int bn_coeffs(const prh_bn_layer& ly, int P, int training, float momentum, float
     hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(cdiv(ly.cout, 128)), dim3(128), 0, st, stat2, P,
                        ly.cout, ly.gamma, ly.beta, ly.running_mean, ly.running_var,
                        ly.num_batches_tracked, momentum, eps, mean, rstd, scale, shift);
+    if (amax_slot != nullptr && ws_c != nullptr && cdiv(ly.cout, 32) * BN_SLICES <= ABSMAX_MAX_BLOCKS) {
+      LAUNCH_CHECK();
+      hipLaunchKernelGGL(act_amax_kernel, dim3(cdiv(ly.cout, 32), BN_SLICES), dim3(256), 0, st, ws_c, ws_d,
+                         si.count, (long)ly.cout, ly.cout, (const float*)scale, (const float*)shift, apart);
+      LAUNCH_CHECK();
+      hipLaunchKernelGGL(absmax_final_kernel, dim3(1), dim3(256), 0, st, (const float*)apart,
+                         cdiv(ly.cout, 32) * BN_SLICES, amax_slot);
+    }
   } else {
     hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(cdiv(ly.cout, 256)), dim3(256), 0, st, ly.gamma,
                        ly.beta, ly.running_mean, ly.running_var, eps, ly.cout, mean, rstd, scale,
@@ -503,7 +524,11 @@ int bn_coeffs(const prh_bn_layer& ly, int P, int training, float momentum, float
 // forward of the stack into z_cat (ld = ldz); coefficient vectors indexed by off_l
 int stack_forward(const prh_bn_layer* ly, int L, const float* x, int P, int training,
                   float momentum, float eps, float* z_cat, long ldz, float* scale, float* shift,
-                  float* mean, float* rstd, StackWS& w, hipStream_t st) {
+                  float* mean, float* rstd, StackWS& w, hipStream_t st, float* op_amax = nullptr) {
+  // op_amax (training): slot l receives the maximum of layer l's activation relu(BN_l(z_l)),
+  // taken from the statistics epilogue - the operand scale of layer l+1's split-fp16 GEMM and,
+  // kept by the caller, of the wgrads in backward: no pass over the activations
+  if (!training || gemm_mode() != 3) op_amax = nullptr;
   StackDims d = stack_dims(ly, L);
   const float* x0 = x; long ldx = d.cin0; const float* w0 = ly[0].w; int k0 = d.cin0;
   if (d.cin0p != d.cin0) {
@@ -516,6 +541,7 @@ int stack_forward(const prh_bn_layer* ly, int L, const float* x, int P, int trai
     p.M = P; p.N = ly[l].cout; p.bias = ly[l].b;
     p.C = z_cat + d.off[l]; p.ldc = ldz;
     p.ws_a = w.ws_a; p.ws_b = w.ws_b; p.wprep = w.wprep;
+    if (op_amax != nullptr) { p.ws_c = w.ws_c; p.ws_d = w.ws_d; if (l > 0) p.amaxA = op_amax + (l - 1); }
     StatInfo si;
     if (l == 0) {
       p.A = x0; p.lda = ldx; p.W = w0; p.ldw = k0; p.K = k0;
@@ -528,7 +554,8 @@ int stack_forward(const prh_bn_layer* ly, int L, const float* x, int P, int trai
       else TRY((launch_nt<PRO_BNRELU, EPI_BIAS>(p, st)));
     }
     TRY(bn_coeffs(ly[l], P, training, momentum, eps, w.ws_a, w.ws_b, w.stat2, si, mean + d.off[l],
-                  rstd + d.off[l], scale + d.off[l], shift + d.off[l], st));
+                  rstd + d.off[l], scale + d.off[l], shift + d.off[l], st, w.ws_c, w.ws_d, w.apart,
+                  op_amax ? op_amax + l : nullptr));
   }
   return PRH_OK;
 }
@@ -545,7 +572,8 @@ int stack_backward(const prh_bn_layer* ly, int L, const float* x, int P, int tra
                    float* dy_cat, long lddy, const float* z_cat, long ldz, const float* scale,
                    const float* shift, const float* mean, const float* rstd,
                    const prh_bn_layer_grad* gr, float* dx, StackWS& w, StackBwdScratch& sc,
-                   StatInfo si, hipStream_t st) {
+                   StatInfo si, hipStream_t st, const float* op_amax = nullptr) {
+  if (!training || gemm_mode() != 3) op_amax = nullptr;   // slots as filled by stack_forward
   StackDims d = stack_dims(ly, L);
   const float* x0 = x; long ldx = d.cin0; int k0 = d.cin0;
   if (d.cin0p != d.cin0) { x0 = w.xpad; ldx = d.cin0p; k0 = d.cin0p; }   // xpad filled by caller
@@ -584,6 +612,7 @@ int stack_backward(const prh_bn_layer* ly, int L, const float* x, int P, int tra
       } else {
         t.B = z_cat + d.off[l - 1]; t.ldb = ldz; t.Ni = ly[l].cin;
         t.qa = scale + d.off[l - 1]; t.qb = shift + d.off[l - 1];
+        if (op_amax != nullptr) t.amaxB = op_amax + (l - 1);
         if (mat) TRY((launch_tn<PRO_NONE, PRO_BNRELU>(t, sc.slab, sc.colslab, gr[l].dw, (long)ly[l].cin, nullptr, st)));
         else TRY((launch_tn<PRO_BNBWD, PRO_BNRELU>(t, sc.slab, sc.colslab, gr[l].dw, (long)ly[l].cin, nullptr, st)));
       }
@@ -880,8 +909,11 @@ int prh_encoder_forward(const prh_encoder_params* prm, const float* ctx, int B, 
   StackWS& w = ews.w;
 
   // conv1..5 (+bn, relu applied on load by the consumer)           src/model.py:43-47
+  // operand maxima from the statistics epilogues (training, split-fp16 cores): slots 0..4 =
+  // activations of conv1..5, slot 5 = their maximum = the fusion conv's operand
+  float* op_amax = (training && gemm_mode() == 3) ? sv->op_amax : nullptr;
   TRY(stack_forward(prm->conv, 5, ctx, P, training, momentum, eps, sv->z_cat, (long)cat,
-                    sv->bn_scale, sv->bn_shift, sv->bn_mean, sv->bn_rstd, w, st));
+                    sv->bn_scale, sv->bn_shift, sv->bn_mean, sv->bn_rstd, w, st, op_amax));
   // fusion conv over the (never materialised) concat               src/model.py:50-51
   {
     NTParams p; memset(&p, 0, sizeof(p));
@@ -889,6 +921,11 @@ int prh_encoder_forward(const prh_encoder_params* prm, const float* ctx, int B, 
     p.pa = sv->bn_scale; p.pb = sv->bn_shift;
     p.M = P; p.N = od; p.bias = prm->fusion.b; p.C = sv->z_fus; p.ldc = od;
     p.ws_a = w.ws_a; p.ws_b = w.ws_b; p.wprep = w.wprep;
+    if (op_amax != nullptr) {
+      hipLaunchKernelGGL(max_of_kernel, dim3(1), dim3(1), 0, st, (const float*)op_amax, 5, op_amax + 5);
+      LAUNCH_CHECK();
+      p.amaxA = op_amax + 5;
+    }
     StatInfo si;
     if (training) TRY((launch_nt<PRO_BNRELU, EPI_BIAS_STATS>(p, st, &si)));
     else TRY((launch_nt<PRO_BNRELU, EPI_BIAS>(p, st)));
@@ -972,6 +1009,7 @@ int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B,
     t.B = sv->z_cat; t.ldb = cat; t.qa = sv->bn_scale; t.qb = sv->bn_shift;
     t.P = P; t.Mo = od; t.Ni = cat;
     t.amaxA = dzf_amax;
+    if (training && gemm_mode() == 3 && sv->op_amax != nullptr) t.amaxB = sv->op_amax + 5;
     if (matf) TRY((launch_tn<PRO_NONE, PRO_BNRELU>(t, fslab, fcslab, gr->fusion.dw, (long)cat, nullptr, st)));
     else TRY((launch_tn<PRO_BNBWD, PRO_BNRELU>(t, fslab, fcslab, gr->fusion.dw, (long)cat, nullptr, st)));
     dzf_amax = t.amaxA;
@@ -997,7 +1035,7 @@ int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B,
   float* dx = d_ctx;
   TRY(stack_backward(prm->conv, 5, ctx, P, training, dy_cat, (long)cat, sv->z_cat, (long)cat,
                      sv->bn_scale, sv->bn_shift, sv->bn_mean, sv->bn_rstd, gr->conv, dx, w, sc, si5,
-                     st));
+                     st, sv->op_amax));
 
   // (4) intensity gate: dW2 = dG^T u, db2 = colsum dG; dU = dG W2 masked by u>0 with
   //     column sums (db1) and intensity-weighted column sums (dw1)

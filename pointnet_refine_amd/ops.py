@@ -254,13 +254,14 @@ class EncoderFn(torch.autograd.Function):
         z_cat = torch.empty((P, cat), dtype=torch.float32, device=dev)
         z_fus = torch.empty((P, out_dim), dtype=torch.float32, device=dev)
         gate = torch.empty((P, out_dim), dtype=torch.float32, device=dev) if need_bwd else None
-        coef = torch.empty((4, cat + out_dim), dtype=torch.float32, device=dev)
+        coef = torch.empty((5, cat + out_dim), dtype=torch.float32, device=dev)   # row 4: operand maxima
         fused = torch.empty((B, N, out_dim), dtype=torch.float32, device=dev)
         gfeat = torch.empty((B, 2 * out_dim), dtype=torch.float32, device=dev) if want_global else None
         argmax = torch.empty((B, out_dim), dtype=torch.int32, device=dev) if (want_global and need_bwd) else None
         prm = _enc_params_struct(p2, buffers, Cin)
+        gemm_mode = L.lib().prh_get_gemm_mode()
         sv = L.EncoderSaved(_p(z_cat), _p(z_fus), _p(gate), _p(coef[0]), _p(coef[1]), _p(coef[2]),
-                            _p(coef[3]), _p(argmax))
+                            _p(coef[3]), _p(argmax), _p(coef[4]) if (training and need_bwd) else None)
         nb = L.lib().prh_encoder_workspace_bytes(B, N, Cin, out_dim, 0)
         ws = _ws(dev, nb)
         L.check(L.lib().prh_encoder_forward(C.byref(prm), _p(x), B, N, int(training), float(momentum),
@@ -271,6 +272,7 @@ class EncoderFn(torch.autograd.Function):
             ctx.save_for_backward(x, z_cat, z_fus, gate, coef, argmax if argmax is not None else coef, *p2)
             ctx.has_argmax = argmax is not None
             ctx.training = int(training)
+            ctx.gemm_mode = gemm_mode
             ctx.pshapes = [t.shape for t in params]
             ctx.consumed = False
         if want_global:
@@ -296,8 +298,10 @@ class EncoderFn(torch.autograd.Function):
                 raise RuntimeError("encoder backward: gradient for global_feat but no argmax saved")
             d_gfeat = d_gfeat.contiguous()
         prm = _enc_params_struct(p2, None, Cin)
+        same_mode = ctx.training and ctx.gemm_mode == L.lib().prh_get_gemm_mode()
         sv = L.EncoderSaved(_p(z_cat), _p(z_fus), _p(gate), _p(coef[0]), _p(coef[1]), _p(coef[2]),
-                            _p(coef[3]), _p(argmax) if ctx.has_argmax else None)
+                            _p(coef[3]), _p(argmax) if ctx.has_argmax else None,
+                            _p(coef[4]) if same_mode else None)
         g = [torch.empty_like(t) for t in p2]
         gr = L.EncoderGrads()
         for k in range(5):
