@@ -84,9 +84,10 @@ typedef struct {
   float* bn_rstd;    /* [cat+out_dim] */
   int32_t* argmax;   /* [B, out_dim]  first arg-max point of the max-pool; NULL = skip */
   float* op_amax;    /* [8] or NULL.  Training with the split-fp16 cores: the forward writes the
-                      * largest activation of conv1..5 (and their maximum) here, taken from the
-                      * statistics epilogues, and the backward reads them as operand scales of
-                      * its wgrads instead of re-measuring.  Pass the same buffer to both calls
+                      * largest activation of conv1..5 ([0..4]), their maximum ([5]) and an upper
+                      * bound of max(fused) ([6]) here, taken from the statistics epilogues, and
+                      * the backward reads them as operand scales of its wgrads instead of
+                      * re-measuring.  Pass the same buffer to both calls
                       * (and keep the GEMM mode unchanged in between), or NULL to both. */
 } prh_encoder_saved;
 
@@ -124,12 +125,22 @@ int prh_linear_forward(const float* x, long ldx, const float* w, const float* b,
                        int rows, int k, int n, int relu, void* workspace, size_t workspace_bytes,
                        int device, void* stream);
 
+/* Same with a caller-supplied device scalar x_amax >= max|x| (NULL = measured by a read pass when
+ * the split-fp16 core serves the GEMM): e.g. prh_encoder_saved.op_amax[6] for context_proj. */
+int prh_linear_forward_ex(const float* x, long ldx, const float* w, const float* b, float* y,
+                          int rows, int k, int n, int relu, const float* x_amax, void* workspace,
+                          size_t workspace_bytes, int device, void* stream);
+
 /* nn.Linear backward: dx = dy W (NULL = skip), dw = dy^T x, db = colsum(dy).
  * n and k multiples of 4. */
 size_t prh_linear_backward_workspace_bytes(int rows, int k, int n);
 int prh_linear_backward(const float* x, long ldx, const float* w, const float* dy, float* dx,
                         float* dw, float* db, int rows, int k, int n, void* workspace,
                         size_t workspace_bytes, int device, void* stream);
+
+int prh_linear_backward_ex(const float* x, long ldx, const float* w, const float* dy, float* dx,
+                           float* dw, float* db, int rows, int k, int n, const float* x_amax,
+                           void* workspace, size_t workspace_bytes, int device, void* stream);
 
 /* Stack of <= PRH_MAX_LAYERS shared-MLP layers applied to x [P,cin0]:
  * LineRefineNet.point_mlp, src/model.py:150-159,200-201 (relu_last = 0).

@@ -51,8 +51,8 @@ class EncoderSaved(C.Structure):
 
 EXPORTS = [
     "prh_encoder_workspace_bytes", "prh_encoder_forward", "prh_encoder_backward",
-    "prh_linear_forward_workspace_bytes", "prh_linear_forward",
-    "prh_linear_backward_workspace_bytes", "prh_linear_backward",
+    "prh_linear_forward_workspace_bytes", "prh_linear_forward", "prh_linear_forward_ex",
+    "prh_linear_backward_workspace_bytes", "prh_linear_backward", "prh_linear_backward_ex",
     "prh_mlp_stack_workspace_bytes", "prh_mlp_stack_forward", "prh_mlp_stack_backward",
     "prh_test_gemm_nt", "prh_test_gemm_tn_workspace_bytes", "prh_test_gemm_tn",
     "prh_profile_enable", "prh_profile_count", "prh_profile_reset", "prh_profile_read",
@@ -102,6 +102,10 @@ def _bind(lib):
                                          sz, i, vp]
     lib.prh_linear_forward.restype = i
     lib.prh_linear_forward.argtypes = [vp, lg, vp, vp, vp, i, i, i, i, vp, sz, i, vp]
+    lib.prh_linear_forward_ex.restype = i
+    lib.prh_linear_forward_ex.argtypes = [vp, lg, vp, vp, vp, i, i, i, i, vp, vp, sz, i, vp]
+    lib.prh_linear_backward_ex.restype = i
+    lib.prh_linear_backward_ex.argtypes = [vp, lg, vp, vp, vp, vp, vp, i, i, i, vp, vp, sz, i, vp]
     lib.prh_linear_forward_workspace_bytes.restype = sz
     lib.prh_linear_forward_workspace_bytes.argtypes = [i, i, i]
     lib.prh_linear_backward_workspace_bytes.restype = sz

@@ -734,9 +734,9 @@ size_t prh_linear_forward_workspace_bytes(int rows, int k, int n) {
   return s3_weight_bytes(n, k) + 512;
 }
 
-int prh_linear_forward(const float* x, long ldx, const float* w, const float* b, float* y,
-                       int rows, int k, int n, int relu, void* workspace, size_t workspace_bytes,
-                       int device, void* stream) {
+int prh_linear_forward_ex(const float* x, long ldx, const float* w, const float* b, float* y,
+                          int rows, int k, int n, int relu, const float* x_amax, void* workspace,
+                          size_t workspace_bytes, int device, void* stream) {
   if (!x || !w || !y || rows < 0 || k <= 0 || n <= 0) return fail(PRH_ERR_ARG, "linear_forward: bad argument");
   HIP_TRY(hipSetDevice(device));
   NTParams p; memset(&p, 0, sizeof(p));
@@ -744,7 +744,14 @@ int prh_linear_forward(const float* x, long ldx, const float* w, const float* b,
   p.M = rows; p.N = n; p.K = k; p.bias = b; p.flags = relu ? F_RELU_OUT : 0;
   if (workspace != nullptr && workspace_bytes >= s3_weight_bytes(n, k) + 256)
     p.wprep = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  p.amaxA = x_amax;
   return launch_nt<PRO_NONE, EPI_BIAS>(p, (hipStream_t)stream);
+}
+int prh_linear_forward(const float* x, long ldx, const float* w, const float* b, float* y,
+                       int rows, int k, int n, int relu, void* workspace, size_t workspace_bytes,
+                       int device, void* stream) {
+  return prh_linear_forward_ex(x, ldx, w, b, y, rows, k, n, relu, nullptr, workspace, workspace_bytes, device,
+                               stream);
 }
 
 size_t prh_linear_backward_workspace_bytes(int rows, int k, int n) {
@@ -753,9 +760,9 @@ size_t prh_linear_backward_workspace_bytes(int rows, int k, int n) {
   return a.off + 256;
 }
 
-int prh_linear_backward(const float* x, long ldx, const float* w, const float* dy, float* dx,
-                        float* dw, float* db, int rows, int k, int n, void* workspace,
-                        size_t workspace_bytes, int device, void* stream) {
+int prh_linear_backward_ex(const float* x, long ldx, const float* w, const float* dy, float* dx,
+                           float* dw, float* db, int rows, int k, int n, const float* x_amax,
+                           void* workspace, size_t workspace_bytes, int device, void* stream) {
   if (!x || !w || !dy || rows < 0 || k <= 0 || n <= 0) return fail(PRH_ERR_ARG, "linear_backward: bad argument");
   if ((k & 3) || (n & 3)) return fail(PRH_ERR_ARG, "linear_backward: k=%d and n=%d must be multiples of 4", k, n);
   HIP_TRY(hipSetDevice(device));
@@ -777,10 +784,17 @@ int prh_linear_backward(const float* x, long ldx, const float* w, const float* d
   if (dw != nullptr || db != nullptr) {
     TNParams t; memset(&t, 0, sizeof(t));
     t.amaxA = dy_amax;
+    t.amaxB = x_amax;
     t.A = dy; t.lda = n; t.B = x; t.ldb = ldx; t.P = rows; t.Mo = n; t.Ni = k;
     TRY((launch_tn<PRO_NONE, PRO_NONE>(t, slab, cslab, dw, (long)k, db, st)));
   }
   return PRH_OK;
+}
+int prh_linear_backward(const float* x, long ldx, const float* w, const float* dy, float* dx,
+                        float* dw, float* db, int rows, int k, int n, void* workspace,
+                        size_t workspace_bytes, int device, void* stream) {
+  return prh_linear_backward_ex(x, ldx, w, dy, dx, dw, db, rows, k, n, nullptr, workspace, workspace_bytes,
+                                device, stream);
 }
 
 // ------------------------------------------------------------------ MLP stack (point_mlp)
@@ -925,12 +939,14 @@ int prh_encoder_forward(const prh_encoder_params* prm, const float* ctx, int B, 
       hipLaunchKernelGGL(max_of_kernel, dim3(1), dim3(1), 0, st, (const float*)op_amax, 5, op_amax + 5);
       LAUNCH_CHECK();
       p.amaxA = op_amax + 5;
+      p.ws_c = w.ws_c; p.ws_d = w.ws_d;      // slot 6: max relu(BN(zf)) >= max of the gated output
     }
     StatInfo si;
     if (training) TRY((launch_nt<PRO_BNRELU, EPI_BIAS_STATS>(p, st, &si)));
     else TRY((launch_nt<PRO_BNRELU, EPI_BIAS>(p, st)));
     TRY(bn_coeffs(prm->fusion, P, training, momentum, eps, w.ws_a, w.ws_b, w.stat2, si, sv->bn_mean + cat,
-                  sv->bn_rstd + cat, sv->bn_scale + cat, sv->bn_shift + cat, st));
+                  sv->bn_rstd + cat, sv->bn_scale + cat, sv->bn_shift + cat, st, w.ws_c, w.ws_d, w.apart,
+                  op_amax ? op_amax + 6 : nullptr));
   }
   // intensity gate GEMM + BN/ReLU/gate combine                     src/model.py:42,51,54-55
   {

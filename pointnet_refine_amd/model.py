@@ -206,8 +206,12 @@ class LineRefineNet(nn.Module):
     # -- accelerated rows -------------------------------------------------------------------
     def encode_context(self, context):
         """context (B,N,4) -> memory (B,N,256): encoder + context_proj (src/model.py:192-194)."""
-        _, fused = self.context_encoder.forward_pointmajor(context, want_global=False)
-        return ops.linear(fused, self.context_proj.weight, self.context_proj.bias)
+        enc = self.context_encoder
+        if context.dim() != 3:
+            raise RuntimeError(f"Expected 3D (batched) input, but got input of size: {list(context.shape)}")
+        _, fused, fused_amax = ops.encoder_with_amax(context, enc._param_list(), enc._bn_buffer_list(), False,
+                                                     enc.training, enc.bn1.momentum, enc.bn1.eps)
+        return ops.linear(fused, self.context_proj.weight, self.context_proj.bias, fused_amax)
 
     def encode_line(self, noisy_line):
         """noisy_line (B,M,3) -> initial queries (B,M,256): point_mlp (src/model.py:200-201)."""

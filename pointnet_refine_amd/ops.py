@@ -61,7 +61,9 @@ class LinearFn(torch.autograd.Function):
     """y = x W^T + b on the fp32 MFMA GEMM core (context_proj, src/model.py:147,194)."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, x_amax=None):
+        """x_amax: optional 1-element device tensor >= max|x| (saves the read pass that places the
+        operand for the split-fp16 core; e.g. the encoder's bound for its output)."""
         _req_gpu_f32(x, "input")
         _req_gpu_f32(w, "weight")
         n, k = w.shape
@@ -76,10 +78,11 @@ class LinearFn(torch.autograd.Function):
         rows = x2.shape[0]
         y = torch.empty((rows, n), dtype=torch.float32, device=x.device)
         ws = _ws(x.device, L.lib().prh_linear_forward_workspace_bytes(rows, k, n))
-        L.check(L.lib().prh_linear_forward(_p(x2), k, _p(w), _p(b), _p(y), rows, k, n, 0, _p(ws),
-                                           ws.numel(), x.device.index, _stream(x.device)),
+        L.check(L.lib().prh_linear_forward_ex(_p(x2), k, _p(w), _p(b), _p(y), rows, k, n, 0, _p(x_amax), _p(ws),
+                                              ws.numel(), x.device.index, _stream(x.device)),
                 "prh_linear_forward")
         ctx.save_for_backward(x2, w)
+        ctx.x_amax = x_amax
         ctx.has_bias = b is not None
         ctx.xshape = x.shape
         return y.reshape(*x.shape[:-1], n)
@@ -101,14 +104,14 @@ class LinearFn(torch.autograd.Function):
         db = torch.empty(n, dtype=torch.float32, device=dev) if need_db else None
         nb = L.lib().prh_linear_backward_workspace_bytes(rows, k, n)
         ws = _ws(dev, nb)
-        L.check(L.lib().prh_linear_backward(_p(x2), k, _p(w), _p(dy2), _p(dx), _p(dw), _p(db), rows,
-                                            k, n, _p(ws), ws.numel(), dev.index, _stream(dev)),
+        L.check(L.lib().prh_linear_backward_ex(_p(x2), k, _p(w), _p(dy2), _p(dx), _p(dw), _p(db), rows,
+                                               k, n, _p(ctx.x_amax), _p(ws), ws.numel(), dev.index, _stream(dev)),
                 "prh_linear_backward")
-        return (dx.reshape(ctx.xshape) if need_dx else None), dw, db
+        return (dx.reshape(ctx.xshape) if need_dx else None), dw, db, None
 
 
-def linear(x, w, b=None):
-    return LinearFn.apply(x, w, b)
+def linear(x, w, b=None, x_amax=None):
+    return LinearFn.apply(x, w, b, x_amax)
 
 
 # ------------------------------------------------------------------------------------------
@@ -275,6 +278,9 @@ class EncoderFn(torch.autograd.Function):
             ctx.gemm_mode = gemm_mode
             ctx.pshapes = [t.shape for t in params]
             ctx.consumed = False
+        # bound of max(fused) from the fusion statistics (training, split-fp16 cores), else None
+        ctx_amax = coef[4, 6:7] if (training and need_bwd and gemm_mode == 3) else None
+        EncoderFn.last_fused_amax = ctx_amax
         if want_global:
             return gfeat, fused
         return None, fused
@@ -321,6 +327,15 @@ class EncoderFn(torch.autograd.Function):
 
 def encoder(x_pm, params, buffers, want_global: bool, training: bool, momentum: float, eps: float):
     return EncoderFn.apply(x_pm, want_global, training, momentum, eps, list(buffers), *params)
+
+
+def encoder_with_amax(x_pm, params, buffers, want_global, training, momentum, eps):
+    """encoder() plus a 1-element device tensor bounding max(fused) from above (None when the
+    forward did not produce one): lets the Linear that consumes `fused` skip its read pass."""
+    EncoderFn.last_fused_amax = None
+    gfeat, fused = EncoderFn.apply(x_pm, want_global, training, momentum, eps, list(buffers), *params)
+    amax, EncoderFn.last_fused_amax = EncoderFn.last_fused_amax, None
+    return gfeat, fused, amax
 
 
 # ------------------------------------------------------------------------------------------
