@@ -252,4 +252,200 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_h2_kernel(const NTParams p,
                           reinterpret_cast<float*>(smem) + wave * (32 * EPI_LDW));
 }
 
+// ---------------------------------------------------------------------------------------
+// TN (wgrad) with ROW-MAJOR staging and transposed fragment reads:
+//   C[Mo,Ni] = sum_p A[p,Mo] * proB(B)[p,Ni] over this split's rows, two scaled fp16 planes.
+// The first TN core stages column-wise (each lane walks down a column with 4-byte loads) so
+// that eight k-values of one column form a 16-B fragment in LDS; its limit is that global
+// staging.  Here the k-tile (16 rows x 256 columns) is loaded as it lies in memory - 16-B
+// loads, a wave per 1-KB row - split, and written ROW-major ([k][column] fp16, 8-B stores,
+// rows padded to 576 B), and the MFMA operands are gathered by ds_read_b64_tr_b16: each
+// 16-lane group reads a 4 (k) x 16 (columns) block and receives it column-major, two reads per
+// 8-deep fragment.  The 576-B row stride puts the four rows of a 32-lane half on disjoint
+// 16-bank ranges.  Plain A operand (dz is materialised), B plain or BN+ReLU; needs Mo, Ni and
+// the leading dimensions to be multiples of 4.  32x32x16 MFMA, 256 x 256 tile, 8 waves as
+// 2 x 4, two staging register sets (loads two k-tiles ahead).
+// ---------------------------------------------------------------------------------------
+typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+constexpr int TR_ROW = 576;                      // bytes per image row: 256 fp16 + 64 B pad
+constexpr int TR_PLANE = 16 * TR_ROW;            // 9216
+constexpr int TR_OPER = 2 * TR_PLANE;            // h, l
+constexpr int TR_STAGE = 2 * TR_OPER;            // A, B
+constexpr int TR_LDS = 2 * TR_STAGE;             // 73728
+
+__device__ __forceinline__ f16x8 tr_fragment(const char* plane, int col0, int lane) {
+  const int g = lane >> 4, j = lane & 15;
+  const char* a = plane + ((g >> 1) * 8 + (j >> 2)) * TR_ROW + (col0 + (g & 1) * 16 + 4 * (j & 3)) * 2;
+  const fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+      (__attribute__((address_space(3))) fp16x4*)(a));
+  const fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+      (__attribute__((address_space(3))) fp16x4*)(a + 4 * TR_ROW));
+  struct Pair { fp16x4 a, b; } pr = {lo, hi};      // k 0..3 | k 4..7 of this lane's half
+  return __builtin_bit_cast(f16x8, pr);
+}
+
+template <int PROB>
+__global__ __launch_bounds__(512, 2) void gemm_tn_tr_kernel(const TNParams p) {
+  static_assert(PROB == PRO_NONE || PROB == PRO_BNRELU, "prologue not supported");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
+  int b = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = b % p.tiles_n; b /= p.tiles_n;
+  const int tile_m = b % p.tiles_m; b /= p.tiles_m;
+  const int split = b;
+  const int m0 = tile_m * 256, n0 = tile_n * 256;
+  const int p_begin = split * p.rows_per_split;
+  int p_end = p_begin + p.rows_per_split;
+  if (p_end > p.P) p_end = p.P;
+  const int KT = (p_end - p_begin + S3_BK - 1) / S3_BK;
+
+  const int c4 = (tid & 63) * 4, r8 = tid >> 6;        // staging: 4 columns, rows r8 and r8 + 8
+  const bool aok = (m0 + c4) < p.Mo, bok = (n0 + c4) < p.Ni;
+  const float sA = pow2_scale(load_amax(p.amaxA)), sB = pow2_scale(load_amax(p.amaxB));
+  const float sAm = aok ? sA : 0.f, sBm = bok ? sB : 0.f;
+  float4 qa = zero4(), qb = zero4();
+  if (PROB == PRO_BNRELU && bok) {
+    qa = ldg4(p.qa + n0 + c4); qb = ldg4(p.qb + n0 + c4);
+    qa.x *= sB; qa.y *= sB; qa.z *= sB; qa.w *= sB; qb.x *= sB; qb.y *= sB; qb.z *= sB; qb.w *= sB;
+  }
+  const bool want_cs = p.colsum != nullptr && tile_n == 0;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nrows = p_end - p_begin > 0 ? p_end - p_begin : 0;
+  int acols = p.Mo - m0; acols = acols > 256 ? 256 : acols;
+  int bcols = p.Ni - n0; bcols = bcols > 256 ? 256 : bcols;
+  const size_t abytes = nrows > 0 ? ((size_t)(nrows - 1) * p.lda + acols) * 4 : 0;
+  const size_t bbytes = nrows > 0 ? ((size_t)(nrows - 1) * p.ldb + bcols) * 4 : 0;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.A + (size_t)p_begin * p.lda + m0), 0, (int)abytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.B + (size_t)p_begin * p.ldb + n0), 0, (int)bbytes, 0x00020000);
+  const int stepA = (int)p.lda * 4, stepB = (int)p.ldb * 4;
+  const int voA = r8 * stepA + c4 * 4, voB = r8 * stepB + c4 * 4;
+
+  float4 va[2][2], vb[2][2];
+  float4 cs = zero4();
+  auto load_tile = [&](int kt, float4 (&xa)[2], float4 (&xb)[2]) {
+    const int oa = voA + kt * S3_BK * stepA, ob = voB + kt * S3_BK * stepB;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      xa[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA, oa + j * 8 * stepA, 0, 0));
+      xb[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsB, ob + j * 8 * stepB, 0, 0));
+    }
+  };
+  auto store_tile = [&](char* st, const float4 (&xa)[2], const float4 (&xb)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float4 a = xa[j];
+      a.x *= sAm; a.y *= sAm; a.z *= sAm; a.w *= sAm;
+      if (want_cs) { cs.x += a.x; cs.y += a.y; cs.z += a.z; cs.w += a.w; }
+      float4 y = xb[j];
+      if (PROB == PRO_BNRELU) {
+        y.x = fmaxf(fmaf(y.x, qa.x, qb.x), 0.f); y.y = fmaxf(fmaf(y.y, qa.y, qb.y), 0.f);
+        y.z = fmaxf(fmaf(y.z, qa.z, qb.z), 0.f); y.w = fmaxf(fmaf(y.w, qa.w, qb.w), 0.f);
+      } else {
+        y.x *= sBm; y.y *= sBm; y.z *= sBm; y.w *= sBm;
+      }
+      uint2 h, l;
+      char* q = st + (r8 + 8 * j) * TR_ROW + c4 * 2;
+      split2h(a.x, a.y, h.x, l.x);
+      split2h(a.z, a.w, h.y, l.y);
+      *reinterpret_cast<uint2*>(q) = h;
+      *reinterpret_cast<uint2*>(q + TR_PLANE) = l;
+      split2h(y.x, y.y, h.x, l.x);
+      split2h(y.z, y.w, h.y, l.y);
+      *reinterpret_cast<uint2*>(q + TR_OPER) = h;
+      *reinterpret_cast<uint2*>(q + TR_OPER + TR_PLANE) = l;
+    }
+  };
+  auto compute = [&](const char* st, auto i0c, auto i1c) {
+    constexpr int I0 = decltype(i0c)::value, I1 = decltype(i1c)::value;
+    f16x8 wh[2], wl[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      wh[j] = tr_fragment(st + TR_OPER, wn + j * 32, lane);
+      wl[j] = tr_fragment(st + TR_OPER + TR_PLANE, wn + j * 32, lane);
+    }
+#pragma unroll
+    for (int i = I0; i < I1; ++i) {
+      const f16x8 ah = tr_fragment(st, wm + i * 32, lane);
+      const f16x8 al = tr_fragment(st + TR_PLANE, wm + i * 32, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+  if (KT > 0) {
+    load_tile(0, va[0], vb[0]);
+    load_tile(1, va[1], vb[1]);
+    store_tile(smem, va[0], vb[0]);
+  }
+  __syncthreads();
+  auto iter = [&](int kt, auto cs_) {
+    constexpr int CS = decltype(cs_)::value;
+    char* cur = smem + (kt & 1) * TR_STAGE;
+    char* nxt = smem + ((kt + 1) & 1) * TR_STAGE;
+    load_tile(kt + 2, va[CS ^ 1], vb[CS ^ 1]);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(cur, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+    __builtin_amdgcn_sched_barrier(0);
+    compute(cur, std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
+    store_tile(nxt, va[CS], vb[CS]);
+#pragma unroll
+    for (int g = 0; g < 12; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+    }
+    __syncthreads();
+  };
+  int kt = 0;
+  for (; kt + 1 < KT; kt += 2) {
+    iter(kt, std::integral_constant<int, 1>{});
+    iter(kt + 1, std::integral_constant<int, 0>{});
+  }
+  if (kt < KT) iter(kt, std::integral_constant<int, 1>{});
+
+  const float unscale = 1.f / (sA * sB);
+  const int half = lane >> 5, l31 = lane & 31;
+  float* out = p.slab + (size_t)split * p.Mo * p.Ni;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int col = n0 + wn + nt * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm + mt * 32 + crow(r, half);
+        if (row < p.Mo && col < p.Ni) out[(size_t)row * p.Ni + col] = acc[mt][nt][r] * unscale;
+      }
+    }
+  if (want_cs) {       // column sums of A: 8 row groups per column quad
+    float4* red = reinterpret_cast<float4*>(smem);      // all LDS reads are behind the last barrier
+    red[tid] = cs;
+    __syncthreads();
+    if (tid < 64) {
+      float4 s = red[tid];
+#pragma unroll
+      for (int g = 1; g < 8; ++g) {
+        const float4 t = red[tid + 64 * g];
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+      }
+      const float inv = 1.f / sA;
+      float* o = p.colsum + (size_t)split * p.Mo + m0 + c4;
+      if (m0 + c4 + 3 < p.Mo) { o[0] = s.x * inv; o[1] = s.y * inv; o[2] = s.z * inv; o[3] = s.w * inv; }
+    }
+  }
+}
+
 }  // namespace prh

@@ -120,6 +120,8 @@ inline int gemm_mode() {
 }
 // PRH_H2_GEN=1 keeps the split-fp16 NT GEMMs on the first-generation core (32x32x16 MFMA, BK 16)
 bool g_h2_gen2 = [] { const char* e = getenv("PRH_H2_GEN"); return !(e && strcmp(e, "1") == 0); }();
+// PRH_TN_TR=0 keeps the split-fp16 wgrads on the column-staged core
+bool g_tn_tr = [] { const char* e = getenv("PRH_TN_TR"); return !(e && strcmp(e, "0") == 0); }();
 inline const char* core_tag() { return gemm_mode() == 2 ? "b1" : (gemm_mode() == 3 ? "h2" : "s3"); }
 
 // largest |pro(A)| over [rows, cols] into *slot; part: ABSMAX_MAX_BLOCKS floats of scratch
@@ -364,9 +366,20 @@ int launch_tn(TNParams& p, float* slab, float* colsum_slab, float* C, long ldc, 
             p.amaxB = hdr + 1;
           }
         }
-        snprintf(nm, sizeof(nm), "gemm_tn_%s<%d,%d> Mo=%d Ni=%d", core_tag(), PROA, PROB, p.Mo, p.Ni);
+        bool tr = false;
+        if constexpr (PROA == PRO_NONE && (PROB == PRO_NONE || PROB == PRO_BNRELU))
+          tr = mode == 3 && g_tn_tr && ((p.Mo | p.Ni | (int)p.lda | (int)p.ldb) & 3) == 0;
+        snprintf(nm, sizeof(nm), "gemm_tn_%s<%d,%d> Mo=%d Ni=%d", tr ? "h2tr" : core_tag(), PROA, PROB, p.Mo, p.Ni);
         ProfScope ps(nm, 2.0 * p.P * (double)p.Mo * p.Ni, by, st);
-        if (mode == 2)
+        if constexpr (PROA == PRO_NONE && (PROB == PRO_NONE || PROB == PRO_BNRELU)) {
+          if (tr) {
+            static const int attr_tr = allow_big_lds(gemm_tn_tr_kernel<PROB>);
+            if (attr_tr != PRH_OK) return attr_tr;
+            hipLaunchKernelGGL((gemm_tn_tr_kernel<PROB>), dim3((unsigned)blocks), dim3(512), TR_LDS, st, p);
+          }
+        }
+        if (tr) {
+        } else if (mode == 2)
           hipLaunchKernelGGL((gemm_tn_s3_kernel<PROA, PROB, 1>), dim3((unsigned)blocks), dim3(512),
                              S3_LDS, st, p);
         else if (mode == 3)
