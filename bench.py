@@ -34,7 +34,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0     # dense v_mfma_f32_32x32x16_bf16
 SPLIT_PRODUCTS = 6                 # bf16 MFMA products per fp32-accurate MAC on the split cores
 SPLIT16_PRODUCTS = 3               # fp16 MFMA products per fp32-accurate MAC on the split-fp16 cores
 DEFAULT_GEMM = "split16"
-PMC_TRAFFIC_FILE = "r01f_pmc_traffic_B4096.json"
+PMC_TRAFFIC_FILE = "r01j_pmc_traffic_B4096.json"
 HBM_PEAK_GBS = 8000.0
 
 
@@ -48,18 +48,20 @@ def pmc_traffic(dname, batch, points, mode):
     if not (os.path.exists(path) and batch == 4096 and points == 1024 and mode == 3):
         return None
     import re
-    m = re.match(r"gemm_(nt|tn)_h2<(\d),(\d)>", dname)
+    m = re.match(r"gemm_(nt|tn)_h2(tr)?<(\d),(\d)>", dname)
     if not m:
         return None
-    if m.group(1) == "tn":      # wgrad: first-generation core, two fp16 planes
-        tmpl = f"prh::gemm_tn_s3_kernel<{m.group(2)}, {m.group(3)}, 2>"
+    if m.group(1) == "tn" and m.group(2):      # wgrad core with transposed fragment reads
+        tmpl = f"prh::gemm_tn_tr_kernel<{m.group(4)}>"
+    elif m.group(1) == "tn":                   # column-staged wgrad core, two fp16 planes
+        tmpl = f"prh::gemm_tn_s3_kernel<{m.group(3)}, {m.group(4)}, 2>"
     else:
-        tmpl = f"prh::gemm_nt_h2_kernel<{m.group(2)}, {m.group(3)}>"
+        tmpl = f"prh::gemm_nt_h2_kernel<{m.group(3)}, {m.group(4)}>"
     cands = [r for r in json.load(open(path)) if r["kernel"] == tmpl]
     if not cands:
         return None
-    r = max(cands, key=lambda r: r["fetch_bytes_per_launch"])      # the fusion-layer launch
-    return r["fetch_bytes_per_launch"] + (r["write_bytes_per_launch"] or 0.0)
+    r = max(cands, key=lambda r: r["fetch_bytes_largest_launch"])      # the fusion-layer launch
+    return r["fetch_bytes_largest_launch"] + (r["write_bytes_largest_launch"] or 0.0)
 
 
 def parse():

@@ -31,11 +31,19 @@ for (name, wgs), m in acc.items():
     wr = m.get("WRITE_SIZE", [])
     if not fe or max(fe) * 2048 < 1e9:
         continue
+    # launches of one template with one grid can still be different layers (every wgrad runs
+    # 768 workgroups): keep the average and the largest launch of the group (dispatch order is
+    # the same in both passes, so index i of the write pass is the same launch)
+    imax = max(range(len(fe)), key=lambda i: fe[i])
     res.append({"kernel": name, "workgroups": wgs, "launches": len(fe),
                 "fetch_bytes_per_launch": sum(fe) / len(fe) * 1024 * 2,
                 "write_bytes_per_launch": (sum(wr) / len(wr) * 1024) if wr else None,
+                "fetch_bytes_largest_launch": fe[imax] * 1024 * 2,
+                "write_bytes_largest_launch": (wr[imax] * 1024) if (wr and len(wr) == len(fe)) else None,
                 "note": "FETCH_SIZE x2 (gfx950 half-count correction), WRITE_SIZE as read; separate --pmc passes"})
-res.sort(key=lambda r: -r["fetch_bytes_per_launch"])
+res.sort(key=lambda r: -r["fetch_bytes_largest_launch"])
 json.dump(res, open(out, "w"), indent=1)
 for r in res[:10]:
-    print(f"{r['kernel'][:48]:48s} wgs={r['workgroups']:7d} n={r['launches']:3d} fetch {r['fetch_bytes_per_launch']/1e9:7.2f} GB  write {(r['write_bytes_per_launch'] or 0)/1e9:7.2f} GB")
+    print(f"{r['kernel'][:48]:48s} wgs={r['workgroups']:7d} n={r['launches']:3d} fetch avg {r['fetch_bytes_per_launch']/1e9:7.2f} GB "
+          f"largest {r['fetch_bytes_largest_launch']/1e9:7.2f} GB  write avg {(r['write_bytes_per_launch'] or 0)/1e9:7.2f} "
+          f"largest {(r['write_bytes_largest_launch'] or 0)/1e9:7.2f} GB")
