@@ -94,3 +94,42 @@ def test_train_step_with_fused_loss_and_adam_matches_torch_path():
     assert worst < 0.03, worst
     la, lb = sa(ctx, noisy, target), sb(ctx, noisy, target)
     assert abs(float(la) - float(lb)) < 1e-4
+
+
+def test_training_trajectory_split_fp16_vs_exact_fp32_cores():
+    """Ten optimiser steps of the full model (dropout off) from the same start on the exact fp32
+    MFMA cores, the split-bf16 cores and the default split-fp16 cores.  Adam's normalised steps
+    amplify fp32-level noise, so two fp32-accurate runs drift apart slowly; a systematic error
+    of a core family would show as a drift well beyond that of the other one.  The split-bf16
+    run (no scaling, 24-bit operands) is the yardstick for the split-fp16 run."""
+    from pointnet_refine_amd import _lib
+    from pointnet_refine_amd.model import LineRefineNet
+    from pointnet_refine_amd.synth import synthetic_batch
+    from pointnet_refine_amd.train_step import TrainStep
+    lib = _lib.lib()
+    ctx, noisy, target = synthetic_batch(64, 1024, torch.device("cuda", 0))
+    old = lib.prh_get_gemm_mode()
+    curves = {}
+    try:
+        for mode in (0, 1, 3):
+            lib.prh_set_gemm_mode(mode)
+            torch.manual_seed(11)
+            m = LineRefineNet().cuda().train()
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.Dropout):
+                    mod.p = 0.0
+                if isinstance(mod, torch.nn.MultiheadAttention):
+                    mod.dropout = 0.0
+            step = TrainStep(m, decoder_chunk=32)
+            curves[mode] = [float(step(ctx, noisy, target)) for _ in range(10)]
+    finally:
+        lib.prh_set_gemm_mode(old)
+    for mode, name in ((0, "exact fp32"), (1, "split-bf16"), (3, "split-fp16")):
+        print(f"loss, {name} cores:", " ".join(f"{v:.5f}" for v in curves[mode]))
+    a, b, c = curves[0], curves[1], curves[3]
+    assert a[-1] < 0.9 * a[0]                                          # it trains
+    assert abs(a[0] - c[0]) < 2e-5 * a[0] and abs(a[0] - b[0]) < 2e-5 * a[0]     # same first loss
+    drift_bf16 = max(abs(x - y) / x for x, y in zip(a, b))
+    drift_fp16 = max(abs(x - y) / x for x, y in zip(a, c))
+    print(f"largest relative drift from the exact cores: split-bf16 {drift_bf16:.2e}, split-fp16 {drift_fp16:.2e}")
+    assert drift_fp16 < 3e-2 and drift_fp16 < 4.0 * drift_bf16 + 1e-3
