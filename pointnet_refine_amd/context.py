@@ -29,6 +29,43 @@ def resample_polyline(points, num_points=32):
     return np.stack([np.interp(t, cum, points[:, k]) for k in range(3)], axis=1)
 
 
+def resample_polylines_device(raw_lines, num_points, device):
+    """resample_polyline for a list of polylines at once, on the device in float64 (padded
+    cumulative arc lengths, searchsorted, linear interpolation = numpy.interp): (L,num_points,3)
+    float64.  Lines with fewer than 2 points give zeros, as in the reference."""
+    L = len(raw_lines)
+    out = torch.zeros((L, num_points, 3), dtype=torch.float64, device=device)
+    lens = [len(l) for l in raw_lines]
+    keep = [i for i, n in enumerate(lens) if n >= 2]
+    if not keep:
+        return out
+    nmax = max(lens[i] for i in keep)
+    pad = np.zeros((len(keep), nmax, 3))
+    cnt = np.zeros(len(keep), dtype=np.int64)
+    for r, i in enumerate(keep):
+        a = np.asarray(raw_lines[i], dtype=np.float64).reshape(-1, 3)
+        pad[r, :len(a)] = a
+        pad[r, len(a):] = a[-1]                 # repeat the end point: zero-length segments
+        cnt[r] = len(a)
+    pts = torch.from_numpy(pad).to(device)
+    seg = (pts[:, 1:] - pts[:, :-1]).norm(dim=2)
+    cum = torch.cat([torch.zeros((len(keep), 1), dtype=torch.float64, device=device), seg.cumsum(1)], 1)
+    total = cum[:, -1:]
+    t = total * torch.linspace(0.0, 1.0, num_points, dtype=torch.float64, device=device)[None, :]
+    t[:, -1] = total[:, 0]
+    # numpy.interp: index of the last knot <= t among the line's own knots
+    n = torch.from_numpy(cnt).to(device)
+    idx = torch.searchsorted(cum, t, right=True) - 1
+    idx = torch.minimum(idx.clamp_(min=0), (n - 2)[:, None])
+    x0, x1 = cum.gather(1, idx), cum.gather(1, idx + 1)
+    w = ((t - x0) / (x1 - x0).clamp_min(1e-300)).clamp_(0.0, 1.0)
+    w = torch.where(x1 > x0, w, torch.zeros_like(w))
+    p0 = pts.gather(1, idx[:, :, None].expand(-1, -1, 3))
+    p1 = pts.gather(1, (idx + 1)[:, :, None].expand(-1, -1, 3))
+    out[torch.tensor(keep, device=device)] = p0 + (p1 - p0) * w[:, :, None]
+    return out
+
+
 def build_contexts_resampled(cloud, dense, line, num_context_points=1024, crop_radius=0.3,
                              decay_scale=2.0, seed=0, max_candidates=None, return_weights=False):
     """cloud (P,4), dense (L,D,3), line (L,M,3) float32 CUDA tensors ->
@@ -70,10 +107,8 @@ def build_contexts(cloud, raw_lines, num_line_points=32, num_context_points=1024
     context (L,N,4), noisy_line (L,M,3) centred, centres (L,3), counts (L,) - the model inputs of
     inference_whole_scene.py:98-126 for every line at once."""
     dev = cloud.device
-    dense = np.stack([resample_polyline(l, DENSE_POINTS) for l in raw_lines]) if len(raw_lines) else np.zeros((0, DENSE_POINTS, 3))
-    line = np.stack([resample_polyline(l, num_line_points) for l in raw_lines]) if len(raw_lines) else np.zeros((0, num_line_points, 3))
-    dense_t = torch.from_numpy(dense).float().to(dev)
-    line_t = torch.from_numpy(line).float().to(dev)
+    dense_t = resample_polylines_device(raw_lines, DENSE_POINTS, dev).float()
+    line_t = resample_polylines_device(raw_lines, num_line_points, dev).float()
     ctx, counts = build_contexts_resampled(cloud, dense_t, line_t, num_context_points, crop_radius, decay_scale,
                                            seed, max_candidates)
     centres = line_t.mean(dim=1)

@@ -56,7 +56,7 @@ t0 = time.perf_counter()
 refined, _ = refine_scene(model, ct, lines, batch_lines=512, seed=1)
 torch.cuda.synchronize()
 t_scene = time.perf_counter() - t0
-print(f"refine_scene: {L} lines end to end (host resampling + contexts + fp32 eval forward in batches of 512 + "
+print(f"refine_scene: {L} lines end to end (device resampling + contexts + fp32 eval forward in batches of 512 + "
       f"copy back) {t_scene * 1e3:.0f} ms = {L / t_scene:.0f} lines/s")
 nb = 16
 t0 = time.perf_counter()

@@ -177,3 +177,15 @@ def test_scene_sample_stream(tmp_path):
         assert float(t.abs().max()) < 1.0 and int(batch["points_in_tube"].min()) > 128
         seen += c.shape[0]
     assert seen == 12
+
+
+def test_device_resampling_matches_numpy_interp():
+    from pointnet_refine_amd.context import resample_polylines_device
+    rng = np.random.default_rng(12)
+    lines = [np.cumsum(rng.normal(0, 1, (n, 3)), 0) * [5, 1, 0.1] for n in (2, 3, 7, 40, 11)]
+    lines.append(np.array([[1.0, 2.0, 3.0]]))                                   # < 2 points: zeros
+    lines.append(np.array([[0.0, 0, 0], [1.0, 0, 0], [1.0, 0, 0], [2.0, 0, 0]]))  # a repeated vertex
+    for n in (32, 200):
+        got = resample_polylines_device(lines, n, torch.device("cuda", 0)).cpu().numpy()
+        for i, l in enumerate(lines):
+            assert np.allclose(got[i], O.arc_resample(l, n), rtol=0, atol=1e-9), (i, n)
