@@ -200,11 +200,14 @@ int prh_context_build(const float* cloud, int npts, const float* dense, int n_de
  *   *loss (+)= sum_{l,e} |pred[l,e] - target[e]| / denom      d_pred[l,e] = sign(.) / denom
  * pred [n_layers, elems], target [elems]; denom = n_layers * elems of the full batch (a
  * micro-batched caller passes the full-batch denominator and accumulate = 1 from the second
- * chunk on); d_pred may be NULL.  loss is a device scalar. */
+ * chunk on); d_pred may be NULL.  loss is a device scalar.
+ * geometry (device float[2] or NULL; elems must be xyz triples): the metrics the reference logs
+ * every step (train_dist.py:190-203): [0] (+)= sum over points |target| / points (initial
+ * point-to-point error), [1] (+)= sum |pred_last - target| / points (refined error). */
 size_t prh_l1_loss_workspace_bytes(void);
 int prh_l1_loss(const float* pred, const float* target, int n_layers, long elems, double denom,
-                int accumulate, float* loss, float* d_pred, void* workspace, size_t workspace_bytes,
-                int device, void* stream);
+                int accumulate, float* loss, float* d_pred, float* geometry, double points,
+                void* workspace, size_t workspace_bytes, int device, void* stream);
 
 /* torch.optim.Adam step (amsgrad off; train.py:40, train_dist.py:150) over flat, 16-byte
  * aligned fp32 buffers of n elements; step counts from 1. */

@@ -133,7 +133,7 @@ def _bind(lib):
     lib.prh_l1_loss_workspace_bytes.restype = C.c_size_t
     lib.prh_l1_loss_workspace_bytes.argtypes = []
     lib.prh_l1_loss.restype = i
-    lib.prh_l1_loss.argtypes = [vp, vp, i, lg, C.c_double, i, vp, vp, vp, C.c_size_t, i, vp]
+    lib.prh_l1_loss.argtypes = [vp, vp, i, lg, C.c_double, i, vp, vp, vp, C.c_double, vp, C.c_size_t, i, vp]
     lib.prh_adam_step.restype = i
     lib.prh_adam_step.argtypes = [vp, vp, vp, vp, lg, f, f, f, f, f, i, i, vp]
     lib.prh_set_gemm_mode.restype = i

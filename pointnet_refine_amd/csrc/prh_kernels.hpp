@@ -426,26 +426,59 @@ __global__ void fill_kernel(float* p, size_t n, float v) {
 // `denom` is passed in (L * elements of the FULL batch) so a micro-batched caller can add
 // chunk losses.  Two-stage deterministic reduction (l1_final_kernel), no atomics.
 // ---------------------------------------------------------------------------------------
+// The geometry metrics the reference logs every step (train_dist.py:190-203, train.py:74-87)
+// ride on the same pass when GEO is set (elements are xyz triples): part[nb + b] = sum over
+// points of |target| (initial error), part[2 nb + b] = sum of |pred_last - target| (refined).
+template <bool GEO>
 __global__ __launch_bounds__(256) void l1_deep_kernel(const float* __restrict__ pred,
                                                       const float* __restrict__ target, int L, long R,
                                                       float inv_denom, float* __restrict__ d_pred,
                                                       float* __restrict__ part) {
-  __shared__ float red[4];
-  float s = 0.f;
+  __shared__ float red[3][4];
+  float s = 0.f, e0 = 0.f, e1 = 0.f;
   const long stride = (long)gridDim.x * 256;
-  for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < R; r += stride) {
-    const float t = target[r];
-    for (int l = 0; l < L; ++l) {
-      const float d = pred[(size_t)l * R + r] - t;
-      s += fabsf(d);
-      if (d_pred != nullptr) d_pred[(size_t)l * R + r] = d > 0.f ? inv_denom : (d < 0.f ? -inv_denom : 0.f);
+  if (!GEO) {
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < R; r += stride) {
+      const float t = target[r];
+      for (int l = 0; l < L; ++l) {
+        const float d = pred[(size_t)l * R + r] - t;
+        s += fabsf(d);
+        if (d_pred != nullptr) d_pred[(size_t)l * R + r] = d > 0.f ? inv_denom : (d < 0.f ? -inv_denom : 0.f);
+      }
+    }
+  } else {
+    const long npts = R / 3;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < npts; q += stride) {
+      float t[3], dl[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 3; ++c) t[c] = target[q * 3 + c];
+      for (int l = 0; l < L; ++l)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const size_t i = (size_t)l * R + q * 3 + c;
+          const float d = pred[i] - t[c];
+          s += fabsf(d);
+          dl[c] = d;                           // the last layer's difference survives the loop
+          if (d_pred != nullptr) d_pred[i] = d > 0.f ? inv_denom : (d < 0.f ? -inv_denom : 0.f);
+        }
+      e0 += sqrtf(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
+      e1 += sqrtf(dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2]);
     }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o);
+    if (GEO) { e0 += __shfl_xor(e0, o); e1 += __shfl_xor(e1, o); }
+  }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = e0; red[2][threadIdx.x >> 6] = e1; }
   __syncthreads();
-  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    if (GEO) {
+      part[gridDim.x + blockIdx.x] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+      part[2 * gridDim.x + blockIdx.x] = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+    }
+  }
 }
 __global__ __launch_bounds__(256) void l1_final_kernel(const float* __restrict__ part, int n, float inv_denom,
                                                        int accumulate, float* __restrict__ loss) {

@@ -1096,25 +1096,40 @@ int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B,
 
 // ------------------------------------------------------------------ loss + optimiser (row f3)
 constexpr int L1_BLOCKS = 1024;
-size_t prh_l1_loss_workspace_bytes(void) { return (size_t)L1_BLOCKS * sizeof(float) + 256; }
+size_t prh_l1_loss_workspace_bytes(void) { return (size_t)3 * L1_BLOCKS * sizeof(float) + 256; }
 int prh_l1_loss(const float* pred, const float* target, int n_layers, long elems, double denom,
-                int accumulate, float* loss, float* d_pred, void* workspace, size_t workspace_bytes,
-                int device, void* stream) {
+                int accumulate, float* loss, float* d_pred, float* geometry, double points,
+                void* workspace, size_t workspace_bytes, int device, void* stream) {
   if (!pred || !target || !loss || n_layers <= 0 || elems <= 0 || !(denom > 0.0))
     return fail(PRH_ERR_ARG, "l1_loss: bad argument");
+  if (geometry != nullptr && (elems % 3 != 0 || !(points > 0.0)))
+    return fail(PRH_ERR_ARG, "l1_loss: geometry metrics need xyz triples and a point count");
   Arena a(workspace, workspace_bytes);
-  float* part = a.f(L1_BLOCKS);
+  float* part = a.f(3 * L1_BLOCKS);
   if (!a.ok) return fail(PRH_ERR_WORKSPACE, "l1_loss: workspace too small (%zu bytes)", workspace_bytes);
   HIP_TRY(hipSetDevice(device));
   hipStream_t st = (hipStream_t)stream;
   long blocks = cdiv(elems, 256L);
   blocks = blocks > L1_BLOCKS ? L1_BLOCKS : blocks;
   const float inv = (float)(1.0 / denom);
-  hipLaunchKernelGGL(l1_deep_kernel, dim3((unsigned)blocks), dim3(256), 0, st, pred, target, n_layers, elems, inv,
-                     d_pred, part);
+  if (geometry != nullptr)
+    hipLaunchKernelGGL(l1_deep_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, pred, target, n_layers,
+                       elems, inv, d_pred, part);
+  else
+    hipLaunchKernelGGL(l1_deep_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, pred, target, n_layers,
+                       elems, inv, d_pred, part);
   LAUNCH_CHECK();
   hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(256), 0, st, (const float*)part, (int)blocks, inv, accumulate, loss);
   LAUNCH_CHECK();
+  if (geometry != nullptr) {
+    const float ip = (float)(1.0 / points);
+    hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(256), 0, st, (const float*)(part + blocks), (int)blocks, ip,
+                       accumulate, geometry);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(256), 0, st, (const float*)(part + 2 * blocks), (int)blocks,
+                       ip, accumulate, geometry + 1);
+    LAUNCH_CHECK();
+  }
   return PRH_OK;
 }
 int prh_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr,

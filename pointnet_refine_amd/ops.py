@@ -498,7 +498,7 @@ class DeepSupervisionL1Fn(torch.autograd.Function):
     (row f3; train.py:63-68, train_dist.py:180-186).  pred (L, ...), target (...)."""
 
     @staticmethod
-    def forward(ctx, pred, target, denom):
+    def forward(ctx, pred, target, denom, geometry=None, points=0.0):
         _req_gpu_f32(pred, "pred")
         _req_gpu_f32(target, "target")
         if pred.shape[1:] != target.shape:
@@ -511,7 +511,8 @@ class DeepSupervisionL1Fn(torch.autograd.Function):
         nb = L.lib().prh_l1_loss_workspace_bytes()
         ws = _ws(dev, nb)
         L.check(L.lib().prh_l1_loss(_p(pred), _p(target), pred.shape[0], target.numel(), float(denom), 0, _p(loss),
-                                    _p(d_pred), _p(ws), ws.numel(), dev.index, _stream(dev)), "prh_l1_loss")
+                                    _p(d_pred), _p(geometry), float(points), _p(ws), ws.numel(), dev.index,
+                                    _stream(dev)), "prh_l1_loss")
         if need:
             ctx.save_for_backward(d_pred)
         return loss
@@ -519,9 +520,20 @@ class DeepSupervisionL1Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (d_pred,) = ctx.saved_tensors
-        return d_pred * g, None, None
+        return d_pred * g, None, None, None, None
 
 
-def deep_supervision_l1(pred, target, denom=None):
-    """(1/L) sum_l mean|pred_l - target| on the HIP path; denom defaults to pred.numel()."""
+def deep_supervision_l1(pred, target, denom=None, geometry=None, points=None):
+    """(1/L) sum_l mean|pred_l - target| on the HIP path; denom defaults to pred.numel().
+    geometry: optional float32 CUDA tensor of 2 elements that ACCUMULATES the step metrics of
+    train_dist.py:190-203 - [0] += mean point-to-point error of the noisy line (|target|),
+    [1] += that of the last layer's prediction - over `points` points (default: this call's)."""
+    if geometry is not None:
+        _req_gpu_f32(geometry, "geometry")
+        points = float(target.numel() // 3 if points is None else points)
+        # the C entry overwrites on accumulate=0: add this call's values to the caller's tensor
+        g = torch.empty(2, dtype=torch.float32, device=pred.device)
+        loss = DeepSupervisionL1Fn.apply(pred, target, float(pred.numel() if denom is None else denom), g, points)
+        geometry += g
+        return loss
     return DeepSupervisionL1Fn.apply(pred, target, float(pred.numel() if denom is None else denom))

@@ -82,11 +82,12 @@ class FlatBuffers:
                 b.copy_(fi[i])
 
 
-def deep_supervision_l1(out, target, denom=None):
+def deep_supervision_l1(out, target, denom=None, geometry=None, points=None):
     """sum_l sum |pred_l - target| / denom, denom = out.numel() by default: (1/L) sum_l
     nn.L1Loss(pred_l, target) of train.py:63-68 / train_dist.py:180-186, as one HIP pass that
-    also produces the gradient (row f3).  GPU tensors only."""
-    return ops.deep_supervision_l1(out, target, denom)
+    also produces the gradient and, into `geometry`, the initial / refined point-to-point errors
+    the reference logs (train_dist.py:190-203) (row f3).  GPU tensors only."""
+    return ops.deep_supervision_l1(out, target, denom, geometry, points)
 
 
 class FlatAdam:
@@ -138,6 +139,7 @@ class TrainStep:
         defaults to the HIP deep-supervision L1 (the reference's loss)."""
         self.model = model
         self.loss_fn = loss_fn if loss_fn is not None else deep_supervision_l1
+        self.geometry = None
         self.chunk = decoder_chunk
         self.world, self.group = world_size, group
         self.grads = FlatGrads(model.parameters())
@@ -145,12 +147,21 @@ class TrainStep:
         distributed = dist.is_available() and dist.is_initialized()
         self.bufs = FlatBuffers(model) if (distributed and broadcast_buffers) else None
 
+    def _loss(self, out, target, denom, points):
+        if self.loss_fn is deep_supervision_l1:        # the HIP loss also fills the step metrics
+            return deep_supervision_l1(out, target, denom, self.geometry, points)
+        return self.loss_fn(out, target, denom)
+
     def forward_backward(self, context, noisy_line, target):
         m = self.model
+        if self.loss_fn is deep_supervision_l1:
+            if self.geometry is None:
+                self.geometry = torch.zeros(2, dtype=torch.float32, device=context.device)
+            self.geometry.zero_()                   # [init_err, refine_err] of this step (device; no sync)
         B = context.shape[0]
         if self.chunk is None or self.chunk >= B or not hasattr(m, "decode"):
             out = m(context, noisy_line)
-            loss = self.loss_fn(out, target, float(out.numel()))
+            loss = self._loss(out, target, float(out.numel()), float(target.numel() // 3))
             loss.backward()
             return loss.detach()
         # encoder side at full batch (BatchNorm statistics span the whole per-rank batch)
@@ -166,7 +177,7 @@ class TrainStep:
             mem_c = mem_d[s:e].requires_grad_()
             tgt_c = tgt_d[s:e].requires_grad_()
             out = m.decode(context[s:e], noisy_line[s:e], mem_c, tgt_c)
-            loss_c = self.loss_fn(out, target[s:e], denom)
+            loss_c = self._loss(out, target[s:e], denom, float(target.numel() // 3))
             loss_c.backward()
             d_memory[s:e] = mem_c.grad
             d_tgt0[s:e] = tgt_c.grad

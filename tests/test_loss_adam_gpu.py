@@ -35,6 +35,16 @@ def test_l1_deep_supervision_matches_torch():
     assert abs(float(whole) - float(parts)) < 1e-6
     with pytest.raises(RuntimeError):
         ops.deep_supervision_l1(pred.cpu(), target.cpu())
+    # geometry metrics of train_dist.py:190-203 on the same pass, accumulated over chunks
+    noisy = torch.randn(64, 32, 3, device="cuda")
+    geo = torch.zeros(2, device="cuda")
+    for s in range(0, 64, 16):
+        ops.deep_supervision_l1(pred[:, s:s + 16].contiguous(), target[s:s + 16].contiguous(), pred.numel(), geo, 64 * 32)
+    line_gt, line_pred = noisy + target, noisy + pred[-1]
+    init_err = (noisy - line_gt).norm(dim=-1).mean()
+    refine_err = (line_pred - line_gt).norm(dim=-1).mean()
+    assert abs(float(geo[0]) - float(init_err)) < 2e-6 * float(init_err)
+    assert abs(float(geo[1]) - float(refine_err)) < 2e-6 * float(refine_err)
 
 
 def test_flat_adam_matches_torch_adam():
