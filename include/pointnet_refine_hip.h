@@ -195,6 +195,22 @@ int prh_context_build(const float* cloud, int npts, const float* dense, int n_de
                       float* dbg_weights, void* workspace, size_t workspace_bytes, int device,
                       void* stream);
 
+/* Row f1, query side of DetrTransformerDecoderLayer (src/model.py:117,128,133):
+ *   y = LayerNorm(x + dropout(r)), nn.LayerNorm(256) semantics (eps, biased variance, affine),
+ * rows x 256 fp32, one pass forward and one backward.  The dropout decision is a counter hash of
+ * (seed, row, channel) - same distribution as nn.Dropout, not the same mask; dropout_p = 0 in
+ * eval mode.  mean/rstd [rows] are saved by the forward for the backward (NULL = not kept).
+ * The backward also produces dgamma / dbeta (sums over rows). */
+int prh_add_dropout_layernorm_forward(const float* x, const float* r, const float* gamma, const float* beta,
+                                      long rows, int channels, float eps, float dropout_p, unsigned seed,
+                                      float* y, float* mean, float* rstd, int device, void* stream);
+size_t prh_add_dropout_layernorm_workspace_bytes(void);
+int prh_add_dropout_layernorm_backward(const float* dy, const float* x, const float* r, const float* gamma,
+                                       const float* mean, const float* rstd, long rows, int channels,
+                                       float dropout_p, unsigned seed, float* dx, float* dr, float* dgamma,
+                                       float* dbeta, void* workspace, size_t workspace_bytes, int device,
+                                       void* stream);
+
 /* Row f3.  Deep-supervision L1 loss with its gradient in one pass (train.py:63-68,
  * train_dist.py:180-186: (1/L) sum_l nn.L1Loss(pred_l, target)):
  *   *loss (+)= sum_{l,e} |pred[l,e] - target[e]| / denom      d_pred[l,e] = sign(.) / denom

@@ -59,6 +59,8 @@ EXPORTS = [
     "prh_attn_forward", "prh_attn_backward",
     "prh_context_workspace_bytes", "prh_context_build",
     "prh_l1_loss_workspace_bytes", "prh_l1_loss", "prh_adam_step",
+    "prh_add_dropout_layernorm_forward", "prh_add_dropout_layernorm_workspace_bytes",
+    "prh_add_dropout_layernorm_backward",
     "prh_set_gemm_mode", "prh_get_gemm_mode",
     "prh_last_error", "prh_version",
 ]
@@ -130,6 +132,13 @@ def _bind(lib):
     lib.prh_context_build.restype = i
     lib.prh_context_build.argtypes = [vp, i, vp, i, vp, i, i, f, f, i, i, C.c_ulonglong, vp, vp, vp, vp,
                                       C.c_size_t, i, vp]
+    lib.prh_add_dropout_layernorm_forward.restype = i
+    lib.prh_add_dropout_layernorm_forward.argtypes = [vp, vp, vp, vp, lg, i, f, f, C.c_uint, vp, vp, vp, i, vp]
+    lib.prh_add_dropout_layernorm_workspace_bytes.restype = C.c_size_t
+    lib.prh_add_dropout_layernorm_workspace_bytes.argtypes = []
+    lib.prh_add_dropout_layernorm_backward.restype = i
+    lib.prh_add_dropout_layernorm_backward.argtypes = [vp, vp, vp, vp, vp, vp, lg, i, f, C.c_uint, vp, vp, vp, vp,
+                                                       vp, C.c_size_t, i, vp]
     lib.prh_l1_loss_workspace_bytes.restype = C.c_size_t
     lib.prh_l1_loss_workspace_bytes.argtypes = []
     lib.prh_l1_loss.restype = i

@@ -531,4 +531,120 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Row f1 (query side of the decoder layer): y = LayerNorm(x + dropout(r)) in one pass, forward
+// and backward (src/model.py:117,128,133: tgt = norm(tgt + dropout(tgt2)), post-norm DETR
+// layer; nn.LayerNorm eps 1e-5, biased variance).  One wave per row of C = 256 channels
+// (4 per lane), reductions by shuffles; the dropout decision is a counter hash of
+// (seed, row, channel) so the backward regenerates it (no mask tensor).
+//   backward: dh = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
+//             dx = dh,  dr = dh * keep/(1-p),  dgamma / dbeta partials per block.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ bool ln_keep(unsigned seed, unsigned row, unsigned col, unsigned thresh) {
+  unsigned x = seed ^ (row * 0x9E3779B1u) ^ (col * 0x85EBCA77u);
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x >= thresh;
+}
+constexpr int LN_C = 256;
+__global__ __launch_bounds__(256) void add_dropout_ln_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ gamma,
+    const float* __restrict__ beta, long rows, float eps, unsigned seed, unsigned thresh, float keep_scale,
+    float* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int c = lane * 4;
+  float4 h = *reinterpret_cast<const float4*>(x + row * LN_C + c);
+  const float4 rv = *reinterpret_cast<const float4*>(r + row * LN_C + c);
+  float* hp = &h.x; const float* rp = &rv.x;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float t = rp[k];
+    if (thresh != 0u) t = ln_keep(seed, (unsigned)row, (unsigned)(c + k), thresh) ? t * keep_scale : 0.f;
+    hp[k] += t;
+  }
+  float s = (h.x + h.y) + (h.z + h.w);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mu = s * (1.f / LN_C);
+  float v = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const float d = hp[k] - mu; v = fmaf(d, d, v); }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  const float rstd = rsqrtf(v * (1.f / LN_C) + eps);
+  const float4 g = *reinterpret_cast<const float4*>(gamma + c), b = *reinterpret_cast<const float4*>(beta + c);
+  float4 o4;
+  o4.x = fmaf((h.x - mu) * rstd, g.x, b.x); o4.y = fmaf((h.y - mu) * rstd, g.y, b.y);
+  o4.z = fmaf((h.z - mu) * rstd, g.z, b.z); o4.w = fmaf((h.w - mu) * rstd, g.w, b.w);
+  *reinterpret_cast<float4*>(y + row * LN_C + c) = o4;
+  if (lane == 0 && mean_out != nullptr) { mean_out[row] = mu; rstd_out[row] = rstd; }
+}
+
+// grid = LN_BWD_BLOCKS blocks of 4 waves; a wave walks rows wave, wave + 4*grid, ...;
+// part_g / part_b [grid][256]: the block's sums of dy*xhat and dy per channel
+constexpr int LN_BWD_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void add_dropout_ln_bwd_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ r,
+    const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd, long rows,
+    unsigned seed, unsigned thresh, float keep_scale, float* __restrict__ dx, float* __restrict__ dr,
+    float* __restrict__ part_g, float* __restrict__ part_b) {
+  __shared__ float sg[4][LN_C], sb[4][LN_C];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane * 4;
+  const float4 g4 = *reinterpret_cast<const float4*>(gamma + c);
+  const float* gp = &g4.x;
+  float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    const float4 d4 = *reinterpret_cast<const float4*>(dy + row * LN_C + c);
+    const float4 x4 = *reinterpret_cast<const float4*>(x + row * LN_C + c);
+    const float4 r4 = *reinterpret_cast<const float4*>(r + row * LN_C + c);
+    const float mu = mean[row], rs = rstd[row];
+    const float* dp = &d4.x; const float* xp = &x4.x; const float* rp = &r4.x;
+    float xh[4], gg[4], kf[4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      kf[k] = 1.f;
+      if (thresh != 0u) kf[k] = ln_keep(seed, (unsigned)row, (unsigned)(c + k), thresh) ? keep_scale : 0.f;
+      xh[k] = (xp[k] + rp[k] * kf[k] - mu) * rs;
+      gg[k] = dp[k] * gp[k];
+      s1 += gg[k];
+      s2 = fmaf(gg[k], xh[k], s2);
+      ag[k] = fmaf(dp[k], xh[k], ag[k]);
+      ab[k] += dp[k];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    const float m1 = s1 * (1.f / LN_C), m2 = s2 * (1.f / LN_C);
+    float4 ox, orr;
+    float* oxp = &ox.x; float* orp = &orr.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float dh = rs * (gg[k] - m1 - xh[k] * m2);
+      oxp[k] = dh;
+      orp[k] = dh * kf[k];
+    }
+    *reinterpret_cast<float4*>(dx + row * LN_C + c) = ox;
+    *reinterpret_cast<float4*>(dr + row * LN_C + c) = orr;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { sg[wave][c + k] = ag[k]; sb[wave][c + k] = ab[k]; }
+  __syncthreads();
+  const int t = threadIdx.x;
+  part_g[(size_t)blockIdx.x * LN_C + t] = (sg[0][t] + sg[1][t]) + (sg[2][t] + sg[3][t]);
+  part_b[(size_t)blockIdx.x * LN_C + t] = (sb[0][t] + sb[1][t]) + (sb[2][t] + sb[3][t]);
+}
+// dgamma[c] = sum_blocks part_g[b][c], dbeta likewise (fp64 accumulation)
+__global__ __launch_bounds__(256) void ln_param_grad_kernel(const float* __restrict__ part_g,
+                                                            const float* __restrict__ part_b, int nb,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = threadIdx.x;
+  double a = 0.0, b = 0.0;
+  for (int i = blockIdx.x; i < nb; i += gridDim.x) { a += (double)part_g[(size_t)i * LN_C + c]; b += (double)part_b[(size_t)i * LN_C + c]; }
+  // gridDim.x == 1 by construction of the launch
+  dgamma[c] = (float)a;
+  dbeta[c] = (float)b;
+}
+
 }  // namespace prh

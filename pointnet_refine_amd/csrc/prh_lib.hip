@@ -1094,6 +1094,52 @@ int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B,
   return PRH_OK;
 }
 
+// ------------------------------------------------------------------ residual + dropout + LayerNorm (row f1)
+static int ln_check(long rows, int channels, float p) {
+  if (rows < 0 || channels != LN_C) return fail(PRH_ERR_ARG, "add_dropout_layernorm: channels must be %d", LN_C);
+  if (p < 0.f || p >= 1.f) return fail(PRH_ERR_ARG, "add_dropout_layernorm: dropout_p must be in [0,1)");
+  return PRH_OK;
+}
+int prh_add_dropout_layernorm_forward(const float* x, const float* r, const float* gamma, const float* beta,
+                                      long rows, int channels, float eps, float dropout_p, unsigned seed,
+                                      float* y, float* mean, float* rstd, int device, void* stream) {
+  if (!x || !r || !gamma || !beta || !y) return fail(PRH_ERR_ARG, "add_dropout_layernorm_forward: null pointer");
+  TRY(ln_check(rows, channels, dropout_p));
+  if (rows == 0) return PRH_OK;
+  HIP_TRY(hipSetDevice(device));
+  const unsigned thresh = dropout_p > 0.f ? (unsigned)((double)dropout_p * 4294967296.0) : 0u;
+  hipLaunchKernelGGL(add_dropout_ln_fwd_kernel, dim3((unsigned)cdiv(rows, 4L)), dim3(256), 0, (hipStream_t)stream, x, r,
+                     gamma, beta, rows, eps, seed, thresh, 1.f / (1.f - dropout_p), y, mean, rstd);
+  LAUNCH_CHECK();
+  return PRH_OK;
+}
+size_t prh_add_dropout_layernorm_workspace_bytes(void) { return (size_t)2 * LN_BWD_BLOCKS * LN_C * sizeof(float) + 256; }
+int prh_add_dropout_layernorm_backward(const float* dy, const float* x, const float* r, const float* gamma,
+                                       const float* mean, const float* rstd, long rows, int channels,
+                                       float dropout_p, unsigned seed, float* dx, float* dr, float* dgamma,
+                                       float* dbeta, void* workspace, size_t workspace_bytes, int device,
+                                       void* stream) {
+  if (!dy || !x || !r || !gamma || !mean || !rstd || !dx || !dr || !dgamma || !dbeta)
+    return fail(PRH_ERR_ARG, "add_dropout_layernorm_backward: null pointer");
+  TRY(ln_check(rows, channels, dropout_p));
+  Arena a(workspace, workspace_bytes);
+  float* pg = a.f((size_t)LN_BWD_BLOCKS * LN_C);
+  float* pb = a.f((size_t)LN_BWD_BLOCKS * LN_C);
+  if (!a.ok) return fail(PRH_ERR_WORKSPACE, "add_dropout_layernorm_backward: workspace too small");
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  long nb = cdiv(rows, 4L * 8);
+  nb = nb < 1 ? 1 : (nb > LN_BWD_BLOCKS ? LN_BWD_BLOCKS : nb);
+  const unsigned thresh = dropout_p > 0.f ? (unsigned)((double)dropout_p * 4294967296.0) : 0u;
+  hipLaunchKernelGGL(add_dropout_ln_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, st, dy, x, r, gamma, mean, rstd, rows,
+                     seed, thresh, 1.f / (1.f - dropout_p), dx, dr, pg, pb);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(ln_param_grad_kernel, dim3(1), dim3(256), 0, st, (const float*)pg, (const float*)pb, (int)nb,
+                     dgamma, dbeta);
+  LAUNCH_CHECK();
+  return PRH_OK;
+}
+
 // ------------------------------------------------------------------ loss + optimiser (row f3)
 constexpr int L1_BLOCKS = 1024;
 size_t prh_l1_loss_workspace_bytes(void) { return (size_t)3 * L1_BLOCKS * sizeof(float) + 256; }

@@ -537,3 +537,64 @@ def deep_supervision_l1(pred, target, denom=None, geometry=None, points=None):
         geometry += g
         return loss
     return DeepSupervisionL1Fn.apply(pred, target, float(pred.numel() if denom is None else denom))
+
+
+class AddDropoutLayerNormFn(torch.autograd.Function):
+    """y = LayerNorm(x + dropout(r)) over the last dimension (256), one HIP pass each way
+    (row f1; src/model.py:117,128,133).  The dropout mask is a counter hash of (seed, row,
+    channel), regenerated in the backward."""
+
+    @staticmethod
+    def forward(ctx, x, r, gamma, beta, eps, p, seed):
+        for t, name in ((x, "x"), (r, "r"), (gamma, "weight"), (beta, "bias")):
+            _req_gpu_f32(t, name)
+        if x.shape != r.shape or x.shape[-1] != 256 or gamma.numel() != 256:
+            raise RuntimeError(f"add_dropout_layernorm: shapes {tuple(x.shape)}, {tuple(r.shape)} (last dim must be 256)")
+        x2, r2 = x.contiguous().view(-1, 256), r.contiguous().view(-1, 256)
+        rows, dev = x2.shape[0], x.device
+        y = torch.empty_like(x2)
+        need = any(ctx.needs_input_grad)
+        mean = torch.empty(rows, dtype=torch.float32, device=dev) if need else None
+        rstd = torch.empty(rows, dtype=torch.float32, device=dev) if need else None
+        L.check(L.lib().prh_add_dropout_layernorm_forward(_p(x2), _p(r2), _p(gamma), _p(beta), rows, 256, float(eps),
+                                                          float(p), int(seed), _p(y), _p(mean), _p(rstd), dev.index,
+                                                          _stream(dev)), "prh_add_dropout_layernorm_forward")
+        if need:
+            ctx.save_for_backward(x2, r2, gamma, mean, rstd)
+            ctx.p, ctx.seed, ctx.shape = float(p), int(seed), x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, r2, gamma, mean, rstd = ctx.saved_tensors
+        dev, rows = x2.device, x2.shape[0]
+        dy2 = dy.contiguous().view(-1, 256)
+        dx, dr = torch.empty_like(x2), torch.empty_like(x2)
+        dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
+        nb = L.lib().prh_add_dropout_layernorm_workspace_bytes()
+        ws = _ws(dev, nb)
+        L.check(L.lib().prh_add_dropout_layernorm_backward(_p(dy2), _p(x2), _p(r2), _p(gamma), _p(mean), _p(rstd), rows,
+                                                           256, ctx.p, ctx.seed, _p(dx), _p(dr), _p(dg), _p(db), _p(ws),
+                                                           ws.numel(), dev.index, _stream(dev)),
+                "prh_add_dropout_layernorm_backward")
+        return dx.view(ctx.shape), dr.view(ctx.shape), dg, db, None, None, None
+
+
+def add_dropout_layernorm(x, r, norm: torch.nn.LayerNorm, p: float):
+    """norm(x + dropout(r, p)); p = 0 in eval mode.  A fresh seed per call from torch's CPU generator."""
+    seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p > 0.0 else 0
+    return AddDropoutLayerNormFn.apply(x, r, norm.weight, norm.bias, norm.eps, p, seed)
+
+
+def layernorm_keep_mask(rows, channels, dropout_p, seed, device="cpu"):
+    """The keep-mask of add_dropout_layernorm re-created with integer tensor ops (tests)."""
+    m32 = 0xFFFFFFFF
+    rr = torch.arange(rows, dtype=torch.int64, device=device).view(-1, 1)
+    cc = torch.arange(channels, dtype=torch.int64, device=device).view(1, -1)
+    x = (int(seed) & m32) ^ ((rr * 0x9E3779B1) & m32) ^ ((cc * 0x85EBCA77) & m32)
+    x = x ^ (x >> 16)
+    x = (x * 0x85EBCA6B) & m32
+    x = x ^ (x >> 13)
+    x = (x * 0xC2B2AE35) & m32
+    x = x ^ (x >> 16)
+    return x >= int(float(dropout_p) * 4294967296.0)

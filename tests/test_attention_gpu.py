@@ -92,3 +92,33 @@ def test_attention_arena_blocks_match_plain_path():
     assert float(ka.grad[..., 3 * C:4 * C].abs().max()) == 0.0       # unused block is zero-filled
     for i in (0, 1, 2, 4, 5):
         assert maxdiff(dq_a[i], q[i].grad) < 1e-6
+
+
+def test_add_dropout_layernorm_fused():
+    """y = LayerNorm(x + dropout(r)) (src/model.py:117,128,133) against torch in fp64, forward and
+    backward, without dropout and with the kernel's own keep-mask re-created in torch."""
+    import torch
+    from pointnet_refine_amd import ops
+    torch.manual_seed(2)
+    for rows, p, seed in ((7, 0.0, 0), (4099, 0.0, 0), (1000, 0.25, 12345), (65, 0.1, 77)):
+        ln = torch.nn.LayerNorm(256).cuda()
+        with torch.no_grad():
+            ln.weight.uniform_(0.5, 1.5); ln.bias.normal_(0, 0.2)
+        x = torch.randn(rows, 256, device="cuda", requires_grad=True)
+        r = (torch.randn(rows, 256, device="cuda") * 3 + 1).requires_grad_(True)
+        w = torch.randn(rows, 256, device="cuda")
+        y = ops.AddDropoutLayerNormFn.apply(x, r, ln.weight, ln.bias, ln.eps, p, seed)
+        (y * w).sum().backward()
+        keep = ops.layernorm_keep_mask(rows, 256, p, seed, "cuda").double() / (1.0 - p) if p > 0 else 1.0
+        x2 = x.detach().double().requires_grad_(True)
+        r2 = r.detach().double().requires_grad_(True)
+        g2 = ln.weight.detach().double().requires_grad_(True)
+        b2 = ln.bias.detach().double().requires_grad_(True)
+        ref = torch.nn.functional.layer_norm(x2 + r2 * keep, (256,), g2, b2, ln.eps)
+        (ref * w.double()).sum().backward()
+        assert maxdiff(y, ref) < 2e-5
+        assert rel_l2(x.grad, x2.grad) < 2e-6 and rel_l2(r.grad, r2.grad) < 2e-6
+        assert rel_l2(ln.weight.grad, g2.grad) < 2e-6 and rel_l2(ln.bias.grad, b2.grad) < 2e-6
+        if p > 0:
+            frac = float(ops.layernorm_keep_mask(rows, 256, p, seed).float().mean())
+            assert abs(frac - (1 - p)) < 0.01
