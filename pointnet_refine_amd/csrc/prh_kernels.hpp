@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256) void add_dropout_ln_fwd_kernel(
 
 // grid = LN_BWD_BLOCKS blocks of 4 waves; a wave walks rows wave, wave + 4*grid, ...;
 // part_g / part_b [grid][256]: the block's sums of dy*xhat and dy per channel
-constexpr int LN_BWD_BLOCKS = 1024;
+constexpr int LN_BWD_BLOCKS = 512;
 __global__ __launch_bounds__(256) void add_dropout_ln_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ r,
     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd, long rows,
@@ -635,16 +635,22 @@ __global__ __launch_bounds__(256) void add_dropout_ln_bwd_kernel(
   part_g[(size_t)blockIdx.x * LN_C + t] = (sg[0][t] + sg[1][t]) + (sg[2][t] + sg[3][t]);
   part_b[(size_t)blockIdx.x * LN_C + t] = (sb[0][t] + sb[1][t]) + (sb[2][t] + sb[3][t]);
 }
-// dgamma[c] = sum_blocks part_g[b][c], dbeta likewise (fp64 accumulation)
+// dgamma[c] = sum_blocks part_g[b][c], dbeta likewise (fp64 accumulation).  grid = 4 blocks of
+// 64 channels; a block's 256 threads = 64 channels x 4 interleaved slices of the partial rows.
 __global__ __launch_bounds__(256) void ln_param_grad_kernel(const float* __restrict__ part_g,
                                                             const float* __restrict__ part_b, int nb,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = threadIdx.x;
+  __shared__ double ra[4][64], rb[4][64];
+  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   double a = 0.0, b = 0.0;
-  for (int i = blockIdx.x; i < nb; i += gridDim.x) { a += (double)part_g[(size_t)i * LN_C + c]; b += (double)part_b[(size_t)i * LN_C + c]; }
-  // gridDim.x == 1 by construction of the launch
-  dgamma[c] = (float)a;
-  dbeta[c] = (float)b;
+  for (int i = sl; i < nb; i += 4) { a += (double)part_g[(size_t)i * LN_C + c]; b += (double)part_b[(size_t)i * LN_C + c]; }
+  ra[sl][cl] = a; rb[sl][cl] = b;
+  __syncthreads();
+  if (sl == 0) {
+    dgamma[c] = (float)((ra[0][cl] + ra[1][cl]) + (ra[2][cl] + ra[3][cl]));
+    dbeta[c] = (float)((rb[0][cl] + rb[1][cl]) + (rb[2][cl] + rb[3][cl]));
+  }
 }
 
 }  // namespace prh

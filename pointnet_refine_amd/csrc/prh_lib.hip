@@ -1134,7 +1134,7 @@ int prh_add_dropout_layernorm_backward(const float* dy, const float* x, const fl
   hipLaunchKernelGGL(add_dropout_ln_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, st, dy, x, r, gamma, mean, rstd, rows,
                      seed, thresh, 1.f / (1.f - dropout_p), dx, dr, pg, pb);
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(ln_param_grad_kernel, dim3(1), dim3(256), 0, st, (const float*)pg, (const float*)pb, (int)nb,
+  hipLaunchKernelGGL(ln_param_grad_kernel, dim3(LN_C / 64), dim3(256), 0, st, (const float*)pg, (const float*)pb, (int)nb,
                      dgamma, dbeta);
   LAUNCH_CHECK();
   return PRH_OK;
