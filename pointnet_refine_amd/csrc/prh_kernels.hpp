@@ -389,6 +389,24 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, int S, int ro
   out[r * ldout + c] = (float)acc;
 }
 
+// the weight-gradient slabs and the bias-gradient (column-sum) slabs of one wgrad in one launch
+__global__ void slab_reduce2_kernel(const float* __restrict__ slab, int S, int rows, int cols, float* out,
+                                    long ldout, const float* __restrict__ cslab, int ccols, float* cout) {
+  const size_t len = (size_t)rows * cols;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < len) {
+    double acc = 0.0;
+    for (int s = 0; s < S; ++s) acc += (double)slab[(size_t)s * len + i];
+    const size_t r = i / cols, c = i - r * cols;
+    out[r * ldout + c] = (float)acc;
+  } else if (i < len + (size_t)ccols) {
+    const size_t j = i - len;
+    double acc = 0.0;
+    for (int s = 0; s < S; ++s) acc += (double)cslab[(size_t)s * ccols + j];
+    cout[j] = (float)acc;
+  }
+}
+
 // dst[r][0..cd) = src[r][0..cs) zero-padded (cd >= cs); or truncation when cd < cs
 __global__ void copy_cols_kernel(const float* __restrict__ src, long lds_, int cs, float* dst,
                                  long ldd, int cd, size_t rows) {

@@ -398,6 +398,13 @@ int launch_tn(TNParams& p, float* slab, float* colsum_slab, float* C, long ldc, 
     }
   }
   LAUNCH_CHECK();
+  if (C != nullptr && colsum_out != nullptr) {      // both reductions of a Linear's wgrad in one launch
+    const size_t len = (size_t)p.Mo * p.Ni + (size_t)p.Mo;
+    hipLaunchKernelGGL(slab_reduce2_kernel, dim3(cdiv((long)len, 256)), dim3(256), 0, st, slab, pl.splits, p.Mo,
+                       p.Ni, C, ldc, (const float*)colsum_slab, p.Mo, colsum_out);
+    LAUNCH_CHECK();
+    return PRH_OK;
+  }
   if (C != nullptr) {
     const size_t len = (size_t)p.Mo * p.Ni;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv((long)len, 256)), dim3(256), 0, st, slab,

@@ -181,7 +181,10 @@ class DetrTransformerDecoderLayer(nn.Module):
             o = _attn(qp, k_proj, v_proj, h, pdrop)
         tgt2 = _lin(o, ca.out_proj.weight, ca.out_proj.bias)
         tgt = _add_norm(tgt, tgt2, self.norm2, self.dropout2, self.training)
-        hid = self.activation(_lin(tgt, self.linear1.weight, self.linear1.bias))
+        if self.activation is F.relu and tgt.is_cuda:      # ReLU rides on the GEMM epilogue
+            hid = ops.linear(tgt, self.linear1.weight, self.linear1.bias, None, True)
+        else:
+            hid = self.activation(_lin(tgt, self.linear1.weight, self.linear1.bias))
         tgt2 = _lin(self.dropout(hid), self.linear2.weight, self.linear2.bias)
         tgt = _add_norm(tgt, tgt2, self.norm3, self.dropout3, self.training)
         return tgt

@@ -61,9 +61,10 @@ class LinearFn(torch.autograd.Function):
     """y = x W^T + b on the fp32 MFMA GEMM core (context_proj, src/model.py:147,194)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, x_amax=None):
+    def forward(ctx, x, w, b, x_amax=None, relu=False):
         """x_amax: optional 1-element device tensor >= max|x| (saves the read pass that places the
-        operand for the split-fp16 core; e.g. the encoder's bound for its output)."""
+        operand for the split-fp16 core; e.g. the encoder's bound for its output).  relu: apply
+        ReLU in the GEMM epilogue (the backward masks dy with y > 0)."""
         _req_gpu_f32(x, "input")
         _req_gpu_f32(w, "weight")
         n, k = w.shape
@@ -78,10 +79,14 @@ class LinearFn(torch.autograd.Function):
         rows = x2.shape[0]
         y = torch.empty((rows, n), dtype=torch.float32, device=x.device)
         ws = _ws(x.device, L.lib().prh_linear_forward_workspace_bytes(rows, k, n))
-        L.check(L.lib().prh_linear_forward_ex(_p(x2), k, _p(w), _p(b), _p(y), rows, k, n, 0, _p(x_amax), _p(ws),
+        L.check(L.lib().prh_linear_forward_ex(_p(x2), k, _p(w), _p(b), _p(y), rows, k, n, int(bool(relu)), _p(x_amax), _p(ws),
                                               ws.numel(), x.device.index, _stream(x.device)),
                 "prh_linear_forward")
-        ctx.save_for_backward(x2, w)
+        if relu:
+            ctx.save_for_backward(x2, w, y)
+        else:
+            ctx.save_for_backward(x2, w)
+        ctx.relu = bool(relu)
         ctx.x_amax = x_amax
         ctx.has_bias = b is not None
         ctx.xshape = x.shape
@@ -89,12 +94,17 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x2, w = ctx.saved_tensors
+        if ctx.relu:
+            x2, w, y = ctx.saved_tensors
+        else:
+            x2, w = ctx.saved_tensors
         n, k = w.shape
         rows = x2.shape[0]
         if n % 4:
             raise RuntimeError("pointnet_refine_amd.linear backward: out_features must be a multiple of 4")
         dy2 = dy.reshape(rows, n)
+        if ctx.relu:
+            dy2 = torch.where(y > 0, dy2, torch.zeros((), dtype=dy2.dtype, device=dy2.device))
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         dev = x2.device
@@ -107,11 +117,11 @@ class LinearFn(torch.autograd.Function):
         L.check(L.lib().prh_linear_backward_ex(_p(x2), k, _p(w), _p(dy2), _p(dx), _p(dw), _p(db), rows,
                                                k, n, _p(ctx.x_amax), _p(ws), ws.numel(), dev.index, _stream(dev)),
                 "prh_linear_backward")
-        return (dx.reshape(ctx.xshape) if need_dx else None), dw, db, None
+        return (dx.reshape(ctx.xshape) if need_dx else None), dw, db, None, None
 
 
-def linear(x, w, b=None, x_amax=None):
-    return LinearFn.apply(x, w, b, x_amax)
+def linear(x, w, b=None, x_amax=None, relu=False):
+    return LinearFn.apply(x, w, b, x_amax, relu)
 
 
 # ------------------------------------------------------------------------------------------

@@ -122,3 +122,24 @@ def test_add_dropout_layernorm_fused():
         if p > 0:
             frac = float(ops.layernorm_keep_mask(rows, 256, p, seed).float().mean())
             assert abs(frac - (1 - p)) < 0.01
+
+
+def test_linear_with_fused_relu():
+    """relu(x W^T + b) with the ReLU in the GEMM epilogue (FFN of the decoder layer,
+    src/model.py:131), forward and backward against torch fp64, on both GEMM paths (small: exact
+    fp32 core, large: split core)."""
+    from pointnet_refine_amd import ops
+    torch.manual_seed(4)
+    for rows in (40, 65536):
+        x = torch.randn(rows, 256, device="cuda", requires_grad=True)
+        w = (torch.randn(1024, 256, device="cuda") * 0.05).requires_grad_(True)
+        b = (torch.randn(1024, device="cuda") * 0.1).requires_grad_(True)
+        g = torch.randn(rows, 1024, device="cuda")
+        y = ops.linear(x, w, b, None, True)
+        (y * g).sum().backward()
+        x2, w2, b2 = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+        ref = torch.relu(torch.nn.functional.linear(x2, w2, b2))
+        (ref * g.double()).sum().backward()
+        assert float(y.min()) >= 0.0 and maxdiff(y, ref) < 2e-5
+        # entries within fp32 noise of zero may take either side of the ReLU: rel-L2 per tensor
+        assert rel_l2(x.grad, x2.grad) < 1e-3 and rel_l2(w.grad, w2.grad) < 1e-3 and rel_l2(b.grad, b2.grad) < 1e-3
