@@ -265,6 +265,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_h2_kernel(const NTParams p,
 // 16-bank ranges.  Plain A operand (dz is materialised), B plain or BN+ReLU; needs Mo, Ni and
 // the leading dimensions to be multiples of 4.  32x32x16 MFMA, 256 x 256 tile, 8 waves as
 // 2 x 4, two staging register sets (loads two k-tiles ahead).
+// (A 16x16x32 / 32-row-k-tile form of this core - 544-B rows with the k-rows permuted so the
+// eight 4-row blocks of a half's gather sit on eight 8-bank ranges - was built and measured:
+// 11.9 vs 12.1 ms on the fusion wgrad, slower on the smaller ones; not kept.)
 // ---------------------------------------------------------------------------------------
 typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 constexpr int TR_ROW = 576;                      // bytes per image row: 256 fp16 + 64 B pad
