@@ -79,6 +79,8 @@ def parse():
                          "products, fp32-level error; split = three bf16 planes, 6 products, fp32-level "
                          "error, no range assumption; fp32 = exact fp32 MFMA everywhere; bf16 = reduced "
                          "precision (config 3)")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture forward+loss+backward in a HIP graph (small, launch-bound batches)")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of the fused flat-buffer Adam")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16)
@@ -157,7 +159,7 @@ def main():
     # optimizer=None: the library's flat-buffer Adam (same update as torch.optim.Adam(lr=1e-3),
     # tests/test_loss_adam_gpu.py), one launch per step; the loss is the fused HIP L1 either way
     opt = torch.optim.Adam(model.parameters(), lr=1e-3) if args.torch_adam else None
-    step = TrainStep(model, opt, decoder_chunk=args.decoder_chunk, world_size=world)
+    step = TrainStep(model, opt, decoder_chunk=args.decoder_chunk, world_size=world, graph=args.graph)
 
     B, N = args.batch, args.points
     ctx, noisy, target = synthetic_batch(B, N, dev, seed=1234 + rank)
@@ -186,6 +188,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    if args.graph:
+        # the library's per-launch events are not recorded inside a replayed graph: one eager
+        # step after the timed region supplies the per-kernel figures of the roofline object
+        lib.prh_profile_reset()
+        step.use_graph = False
+        step(ctx, noisy, target)
+        step.use_graph = True
+        sync()
     # per-kernel live durations (HIP events on the launch stream)
     agg = {}
     name = C.create_string_buffer(64)

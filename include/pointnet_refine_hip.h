@@ -246,6 +246,13 @@ int prh_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 int prh_set_gemm_mode(int mode);
 int prh_get_gemm_mode(void);
 
+/* Dropout under graph replay.  The attention and LayerNorm entry points take their dropout seed
+ * as a host value, which a captured graph would freeze.  Register a device word here (process-
+ * wide, like the GEMM mode; NULL = none): every dropout decision then hashes seed ^ f(*word),
+ * read at kernel run time, so a caller that advances the word on the device before each replay
+ * gets fresh masks while forward and backward of one step still agree. */
+int prh_set_dropout_seed_source(const unsigned* device_word);
+
 /* Raw GEMM cores, exported for the unit tests (tests/test_gemm_gpu.py).
  *   nt: c[m,n] = a[m,k] w[n,k]^T     tn: c[mo,ni] = a[p,mo]^T b[p,ni]          */
 int prh_test_gemm_nt(const float* a, const float* w, float* c, int m, int n, int k,

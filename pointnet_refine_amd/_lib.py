@@ -61,7 +61,7 @@ EXPORTS = [
     "prh_l1_loss_workspace_bytes", "prh_l1_loss", "prh_adam_step",
     "prh_add_dropout_layernorm_forward", "prh_add_dropout_layernorm_workspace_bytes",
     "prh_add_dropout_layernorm_backward",
-    "prh_set_gemm_mode", "prh_get_gemm_mode",
+    "prh_set_gemm_mode", "prh_get_gemm_mode", "prh_set_dropout_seed_source",
     "prh_last_error", "prh_version",
 ]
 
@@ -147,6 +147,8 @@ def _bind(lib):
     lib.prh_adam_step.argtypes = [vp, vp, vp, vp, lg, f, f, f, f, f, i, i, vp]
     lib.prh_set_gemm_mode.restype = i
     lib.prh_set_gemm_mode.argtypes = [i]
+    lib.prh_set_dropout_seed_source.restype = i
+    lib.prh_set_dropout_seed_source.argtypes = [vp]
     lib.prh_get_gemm_mode.restype = i
     lib.prh_profile_enable.restype = i
     lib.prh_profile_enable.argtypes = [i]

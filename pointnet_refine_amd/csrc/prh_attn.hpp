@@ -46,7 +46,17 @@ struct AttnParams {
   float keep_scale;              // 1/(1-p)
   unsigned drop_thresh;          // drop iff hash < thresh (0: no dropout)
   unsigned seed;
+  const unsigned* seed_src;   // optional device word mixed into the seed (graph replays: a counter
+                              // the caller advances on the device, so every replay draws new masks)
 };
+
+// effective seed of a launch: the host value, mixed with the device word when one is registered
+// (read through to L2: the word is rewritten between launches)
+__device__ __forceinline__ unsigned effective_seed(unsigned seed, const unsigned* src) {
+  if (src == nullptr) return seed;
+  const unsigned w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return seed ^ (__builtin_amdgcn_readfirstlane(w) * 0x9E3779B9u);
+}
 
 // counter-based dropout decision, a function of (seed, segment*head, query, key) only, so the
 // forward and the two orientations of the backward agree (tests re-create it in torch)
@@ -87,6 +97,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   const int h2 = lane >> 5, l31 = lane & 31;
   const int hpb = p.H / 4;                          // blocks per segment
   const int b = blockIdx.x / hpb, h = (blockIdx.x % hpb) * 4 + wave;
+  const unsigned seed_eff = effective_seed(p.seed, p.seed_src);
   float* vt = smem + wave * AT_TILE;                // this wave's V tile
   const int col0 = h * 32;
   const unsigned bh = (unsigned)(b * p.H + h);
@@ -136,7 +147,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
         psum += e;
         float pd = e;
         if (p.drop_thresh != 0u)
-          pd = attn_keep(p.seed, bh, (unsigned)(qt + l31), (unsigned)(k0 + crow(r, h2)), p.drop_thresh)
+          pd = attn_keep(seed_eff, bh, (unsigned)(qt + l31), (unsigned)(k0 + crow(r, h2)), p.drop_thresh)
                    ? e * p.keep_scale : 0.f;
         s[r] = pd;
         oacc[r] *= alpha;
@@ -171,6 +182,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnParams p) {
   const int h2 = lane >> 5, l31 = lane & 31;
   const int hpb = p.H / 4;
   const int b = blockIdx.x / hpb, h = (blockIdx.x % hpb) * 4 + wave;
+  const unsigned seed_eff = effective_seed(p.seed, p.seed_src);
   float* qtile = dsm + wave * (4 * AT_TILE);
   float* dotile = qtile + AT_TILE;
   float* ktile = dotile + AT_TILE;
@@ -238,7 +250,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnParams p) {
         float pr = (key_ok && q < p.M) ? __expf(s[r] - lse_row[r]) : 0.f;
         float keepf = 1.f;
         if (p.drop_thresh != 0u)
-          keepf = attn_keep(p.seed, bh, (unsigned)q, (unsigned)(k0 + l31), p.drop_thresh) ? p.keep_scale : 0.f;
+          keepf = attn_keep(seed_eff, bh, (unsigned)q, (unsigned)(k0 + l31), p.drop_thresh) ? p.keep_scale : 0.f;
         const float ds = pr * (dp[r] * keepf - dl_row[r]);
         s[r] = pr * keepf;                            // Pd
         dp[r] = ds;                                   // dS
@@ -290,7 +302,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnParams p) {
         const float pr = (key < p.N && qcol < p.M) ? __expf(s[r] - lse_col) : 0.f;
         float keepf = 1.f;
         if (p.drop_thresh != 0u)
-          keepf = attn_keep(p.seed, bh, (unsigned)qcol, (unsigned)key, p.drop_thresh) ? p.keep_scale : 0.f;
+          keepf = attn_keep(seed_eff, bh, (unsigned)qcol, (unsigned)key, p.drop_thresh) ? p.keep_scale : 0.f;
         dp[r] = pr * (dp[r] * keepf - dl_col);       // dS^T
       }
 #pragma unroll

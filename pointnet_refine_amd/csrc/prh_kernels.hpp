@@ -563,11 +563,19 @@ __device__ __forceinline__ bool ln_keep(unsigned seed, unsigned row, unsigned co
   x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
   return x >= thresh;
 }
+// host seed mixed with the optional device word (see effective_seed in prh_attn.hpp)
+__device__ __forceinline__ unsigned ln_seed(unsigned seed, const unsigned* src) {
+  if (src == nullptr) return seed;
+  const unsigned w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return seed ^ (__builtin_amdgcn_readfirstlane(w) * 0x9E3779B9u);
+}
 constexpr int LN_C = 256;
 __global__ __launch_bounds__(256) void add_dropout_ln_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ r, const float* __restrict__ gamma,
-    const float* __restrict__ beta, long rows, float eps, unsigned seed, unsigned thresh, float keep_scale,
-    float* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    const float* __restrict__ beta, long rows, float eps, unsigned seed_host, const unsigned* seed_src,
+    unsigned thresh, float keep_scale, float* __restrict__ y, float* __restrict__ mean_out,
+    float* __restrict__ rstd_out) {
+  const unsigned seed = ln_seed(seed_host, seed_src);
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -605,9 +613,10 @@ constexpr int LN_BWD_BLOCKS = 512;
 __global__ __launch_bounds__(256) void add_dropout_ln_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ r,
     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd, long rows,
-    unsigned seed, unsigned thresh, float keep_scale, float* __restrict__ dx, float* __restrict__ dr,
-    float* __restrict__ part_g, float* __restrict__ part_b) {
+    unsigned seed_host, const unsigned* seed_src, unsigned thresh, float keep_scale, float* __restrict__ dx,
+    float* __restrict__ dr, float* __restrict__ part_g, float* __restrict__ part_b) {
   __shared__ float sg[4][LN_C], sb[4][LN_C];
+  const unsigned seed = ln_seed(seed_host, seed_src);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane * 4;
   const float4 g4 = *reinterpret_cast<const float4*>(gamma + c);

@@ -106,6 +106,7 @@ struct Arena {
 // -1: not initialised, 0: fp32 cores only, 1: split-bf16 (3 planes, 6 products, fp32-accurate)
 // for large GEMMs, 2: plain bf16 operands (1 plane) for large GEMMs - reduced precision,
 // opt-in only, 3: split-fp16 (2 scaled planes, 3 products, fp32-accurate) for large GEMMs
+const unsigned* g_seed_src = nullptr;   // device word mixed into every dropout seed (prh_set_dropout_seed_source)
 int g_gemm_mode = -1;
 inline int gemm_mode() {
   if (g_gemm_mode < 0) {
@@ -746,6 +747,10 @@ int prh_set_gemm_mode(int mode) {
   return PRH_OK;
 }
 int prh_get_gemm_mode(void) { return gemm_mode(); }
+int prh_set_dropout_seed_source(const unsigned* device_word) {
+  g_seed_src = device_word;
+  return PRH_OK;
+}
 const char* prh_version(void) { return "pointnet_refine_hip 0.3 (gfx950: fp32 MFMA 32x32x2 + split-fp16 / split-bf16 MFMA 32x32x16 cores)"; }
 
 // ------------------------------------------------------------------ Linear
@@ -1116,7 +1121,8 @@ int prh_add_dropout_layernorm_forward(const float* x, const float* r, const floa
   HIP_TRY(hipSetDevice(device));
   const unsigned thresh = dropout_p > 0.f ? (unsigned)((double)dropout_p * 4294967296.0) : 0u;
   hipLaunchKernelGGL(add_dropout_ln_fwd_kernel, dim3((unsigned)cdiv(rows, 4L)), dim3(256), 0, (hipStream_t)stream, x, r,
-                     gamma, beta, rows, eps, seed, thresh, 1.f / (1.f - dropout_p), y, mean, rstd);
+                     gamma, beta, rows, eps, seed, (const unsigned*)g_seed_src, thresh, 1.f / (1.f - dropout_p), y, mean,
+                     rstd);
   LAUNCH_CHECK();
   return PRH_OK;
 }
@@ -1139,7 +1145,7 @@ int prh_add_dropout_layernorm_backward(const float* dy, const float* x, const fl
   nb = nb < 1 ? 1 : (nb > LN_BWD_BLOCKS ? LN_BWD_BLOCKS : nb);
   const unsigned thresh = dropout_p > 0.f ? (unsigned)((double)dropout_p * 4294967296.0) : 0u;
   hipLaunchKernelGGL(add_dropout_ln_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, st, dy, x, r, gamma, mean, rstd, rows,
-                     seed, thresh, 1.f / (1.f - dropout_p), dx, dr, pg, pb);
+                     seed, (const unsigned*)g_seed_src, thresh, 1.f / (1.f - dropout_p), dx, dr, pg, pb);
   LAUNCH_CHECK();
   hipLaunchKernelGGL(ln_param_grad_kernel, dim3(LN_C / 64), dim3(256), 0, st, (const float*)pg, (const float*)pb, (int)nb,
                      dgamma, dbeta);
@@ -1270,7 +1276,7 @@ int prh_attn_forward(const float* q, long ldq, const float* k, long ldk, const f
                      float dropout_p, unsigned seed, int device, void* stream) {
   AttnParams a; memset(&a, 0, sizeof(a));
   a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.o = o; a.ldo = ldo; a.lse = lse;
-  a.B = B; a.M = M; a.N = N; a.H = H; a.scale = scale; a.seed = seed;
+  a.B = B; a.M = M; a.N = N; a.H = H; a.scale = scale; a.seed = seed; a.seed_src = g_seed_src;
   if (dropout_p < 0.f || dropout_p >= 1.f) return fail(PRH_ERR_ARG, "attention: dropout_p must be in [0,1)");
   a.keep_scale = 1.f / (1.f - dropout_p);
   a.drop_thresh = dropout_p > 0.f ? (unsigned)((double)dropout_p * 4294967296.0) : 0u;
@@ -1292,7 +1298,7 @@ int prh_attn_backward(const float* q, long ldq, const float* k, long ldk, const 
   a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.o = (float*)o; a.ldo = ldo;
   a.lse = (float*)lse; a.dout = dout; a.lddo = lddo; a.dq = dq; a.lddq = lddq; a.dk = dk; a.lddk = lddk;
   a.dv = dv; a.lddv = lddv;
-  a.B = B; a.M = M; a.N = N; a.H = H; a.scale = scale; a.seed = seed;
+  a.B = B; a.M = M; a.N = N; a.H = H; a.scale = scale; a.seed = seed; a.seed_src = g_seed_src;
   if (dropout_p < 0.f || dropout_p >= 1.f) return fail(PRH_ERR_ARG, "attention: dropout_p must be in [0,1)");
   a.keep_scale = 1.f / (1.f - dropout_p);
   a.drop_thresh = dropout_p > 0.f ? (unsigned)((double)dropout_p * 4294967296.0) : 0u;

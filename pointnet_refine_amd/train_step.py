@@ -133,13 +133,19 @@ class FlatAdam:
 
 class TrainStep:
     def __init__(self, model, optimizer=None, decoder_chunk: Optional[int] = None, world_size: int = 1,
-                 group=None, broadcast_buffers: bool = True, lr: float = 1e-3, loss_fn=None):
+                 group=None, broadcast_buffers: bool = True, lr: float = 1e-3, loss_fn=None,
+                 graph: bool = False):
         """optimizer = None: the fused flat-buffer Adam (FlatAdam, the reference's Adam(lr=1e-3));
         any torch optimizer over model.parameters() also works.  loss_fn(out, target, denom):
-        defaults to the HIP deep-supervision L1 (the reference's loss)."""
+        defaults to the HIP deep-supervision L1 (the reference's loss).
+        graph = True: forward + loss + backward are captured once into a HIP graph (fixed batch
+        shape) and replayed - for the launch-bound small-batch regime (the reference trains at 32
+        segments per GPU: ~2,000 launches of a few microseconds each).  Dropout stays random per
+        step: the library mixes a device counter, advanced inside the graph, into every seed."""
         self.model = model
         self.loss_fn = loss_fn if loss_fn is not None else deep_supervision_l1
         self.geometry = None
+        self.use_graph, self._graph, self._static = bool(graph), None, None
         self.chunk = decoder_chunk
         self.world, self.group = world_size, group
         self.grads = FlatGrads(model.parameters())
@@ -186,12 +192,47 @@ class TrainStep:
         torch.autograd.backward([memory, tgt0], [d_memory, d_tgt0])
         return total
 
+    def _capture(self, context, noisy_line, target):
+        """Warm up on a side stream, then capture zero-grad + forward + loss + backward."""
+        import ctypes as C
+        from . import _lib as L
+        dev = context.device
+        self._seed = torch.zeros(1, dtype=torch.int32, device=dev)
+        L.check(L.lib().prh_set_dropout_seed_source(C.c_void_p(self._seed.data_ptr())), "prh_set_dropout_seed_source")
+        self._static = [t.clone() for t in (context, noisy_line, target)]
+        if self.loss_fn is deep_supervision_l1 and self.geometry is None:
+            self.geometry = torch.zeros(2, dtype=torch.float32, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):                      # allocations, workspaces, lazy initialisation
+                self._seed.add_(1)
+                self.grads.flat.zero_()
+                self.forward_backward(*self._static)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._seed.add_(1)
+            self.grads.flat.zero_()
+            self._static_loss = self.forward_backward(*self._static)
+
     def __call__(self, context, noisy_line, target):
         if self.bufs is not None:
             with torch.no_grad():
                 self.bufs.broadcast(self.group)
-        self.grads.zero()
-        loss = self.forward_backward(context, noisy_line, target)
+        if self.use_graph:
+            if self._graph is None:
+                self.grads.rebind()
+                self._capture(context, noisy_line, target)
+            for dst, src in zip(self._static, (context, noisy_line, target)):
+                if dst.shape != src.shape:
+                    raise RuntimeError("TrainStep(graph=True): the batch shape is fixed at capture time")
+                dst.copy_(src)
+            self._graph.replay()
+            loss = self._static_loss
+        else:
+            self.grads.zero()
+            loss = self.forward_backward(context, noisy_line, target)
         self.grads.all_reduce_mean(self.world, self.group)
         self.opt.step()
         return loss

@@ -147,3 +147,36 @@ def test_training_trajectory_split_fp16_vs_exact_fp32_cores():
     # but they stay on the same loss curve
     assert max(drift_fp16[:3]) < 5e-4 and max(drift_bf16[:3]) < 5e-4
     assert max(drift_fp16) < 5e-2 and max(drift_bf16) < 5e-2
+
+
+def test_graph_captured_step_matches_eager_step():
+    """TrainStep(graph=True): forward + loss + backward captured once, replayed per step.  With
+    dropout off the replays must reproduce the eager steps; with dropout on, consecutive replays
+    must draw different masks (device-side seed counter) yet stay finite and train."""
+    from pointnet_refine_amd import _lib
+    from pointnet_refine_amd.model import LineRefineNet
+    from pointnet_refine_amd.synth import synthetic_batch
+    from pointnet_refine_amd.train_step import TrainStep
+    ctx, noisy, target = synthetic_batch(8, 256, torch.device("cuda", 0))
+    try:
+        losses = {}
+        for graph in (False, True):
+            torch.manual_seed(21)
+            m = LineRefineNet().cuda().train()
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.Dropout):
+                    mod.p = 0.0
+                if isinstance(mod, torch.nn.MultiheadAttention):
+                    mod.dropout = 0.0
+            step = TrainStep(m, decoder_chunk=4, graph=graph)
+            losses[graph] = [float(step(ctx, noisy, target)) for _ in range(4)]
+        for a, b in zip(losses[False], losses[True]):
+            assert abs(a - b) < 2e-4 * max(a, 1e-3), (losses[False], losses[True])
+        # dropout on: the same weights and inputs give different losses on consecutive replays
+        torch.manual_seed(22)
+        m = LineRefineNet().cuda().train()
+        step = TrainStep(m, torch.optim.SGD(m.parameters(), lr=0.0), decoder_chunk=4, graph=True)
+        l3 = [float(step(ctx, noisy, target)) for _ in range(3)]
+        assert all(torch.isfinite(torch.tensor(l3))) and len({round(v, 7) for v in l3}) == 3, l3
+    finally:
+        _lib.lib().prh_set_dropout_seed_source(None)
