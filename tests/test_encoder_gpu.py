@@ -152,3 +152,39 @@ def test_linear_fwd_bwd():
     assert maxdiff(out, torch.nn.functional.linear(x.double(), w.double(), b.double())) < 1e-4
     for a, bb in zip(xs, ys):
         assert rel_l2(a.grad, bb.grad) < 1e-5
+
+
+def test_encoder_train_ragged_large_vs_oracle_on_split_cores():
+    """Train-mode encoder at a size that engages the default split-fp16 cores (NT second
+    generation, transposed-read wgrad, in-place dz, operand maxima from the statistics epilogue)
+    with NOTHING aligned: P = 5 x 1999 = 9995 rows (not a multiple of the 256-row tile, of the
+    128-row statistics block or of the 16/32-row k-tiles), against the oracle, forward and
+    backward with gradients arriving on both outputs."""
+    C, B, N = 4, 5, 1999
+    sd = P.encoder_state_dict(C, 1024, seed=9)
+    ctx, _, _ = P.synth_batch(B, N, C, 32, seed=31)
+    r = np.random.default_rng(6)
+    up_g = torch.from_numpy(r.normal(0, 1, (B, 2048)).astype(np.float32))
+    up_f = torch.from_numpy(r.normal(0, 1, (B, N, 1024)).astype(np.float32))
+    m = _encoder(C, sd).train()
+    x = ctx.cuda().requires_grad_(True)
+    gf, fu_cm = m(x.transpose(2, 1))
+    ((gf * up_g.cuda()).sum() + (fu_cm.transpose(2, 1) * up_f.cuda()).sum()).backward()
+    p = O.as_params(sd, requires_grad=True)
+    ox = ctx.clone().requires_grad_(True)
+    ns = {}
+    o_g, o_f = O.encoder_forward(p, ox, "", True, ns)
+    ((o_g * up_g).sum() + (o_f * up_f).sum()).backward()
+    assert maxdiff(gf, o_g) < 1e-4 and maxdiff(fu_cm.transpose(2, 1), o_f) < 1e-4
+    assert rel_l2(ox.grad, x.grad) < 5e-3
+    rels = {}
+    named = dict(m.named_parameters())
+    for k, v in named.items():
+        if _pre_bn_bias(k):
+            continue
+        rels[k] = rel_l2(p[k].grad.reshape(v.shape), v.grad)
+    assert max(rels.values()) < 1e-2, max(rels, key=rels.get)
+    assert float(np.median(list(rels.values()))) < 2e-3
+    msd = m.state_dict()
+    for k, v in ns.items():
+        assert maxdiff(msd[k], v) <= 1e-5 * float(v.double().abs().max()) + 1e-6, k
