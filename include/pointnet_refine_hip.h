@@ -138,9 +138,11 @@ int prh_linear_backward(const float* x, long ldx, const float* w, const float* d
                         float* dw, float* db, int rows, int k, int n, void* workspace,
                         size_t workspace_bytes, int device, void* stream);
 
+/* x_amax, dy_amax: optional device scalars bounding max|x| / max|dy| from above (NULL = measured) */
 int prh_linear_backward_ex(const float* x, long ldx, const float* w, const float* dy, float* dx,
                            float* dw, float* db, int rows, int k, int n, const float* x_amax,
-                           void* workspace, size_t workspace_bytes, int device, void* stream);
+                           const float* dy_amax, void* workspace, size_t workspace_bytes, int device,
+                           void* stream);
 
 /* Stack of <= PRH_MAX_LAYERS shared-MLP layers applied to x [P,cin0]:
  * LineRefineNet.point_mlp, src/model.py:150-159,200-201 (relu_last = 0).
@@ -230,6 +232,15 @@ int prh_l1_loss(const float* pred, const float* target, int n_layers, long elems
 int prh_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr,
                   float beta1, float beta2, float eps, float weight_decay, int step, int device,
                   void* stream);
+
+/* prh_attn_backward that also reports, per wave, the largest |dV| and |dK| it stored:
+ * kv_amax_part [B*(H/4)*4][2] (or NULL) - reduced by the caller, it bounds the gradient operand
+ * of the K/V projection's backward GEMMs (prh_linear_backward_ex dy_amax). */
+int prh_attn_backward_ex(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
+                         const float* o, long ldo, const float* lse, const float* dout, long lddo,
+                         float* dq, long lddq, float* dk, long lddk, float* dv, long lddv, int B, int M,
+                         int N, int H, float scale, float dropout_p, unsigned seed, float* kv_amax_part,
+                         int device, void* stream);
 
 /* GEMM core selection (environment PRH_GEMM, or prh_set_gemm_mode at run time):
  *   split16 / 3 (default): large GEMMs on the split-fp16 cores - two fp16 planes per fp32 operand

@@ -56,7 +56,7 @@ EXPORTS = [
     "prh_mlp_stack_workspace_bytes", "prh_mlp_stack_forward", "prh_mlp_stack_backward",
     "prh_test_gemm_nt", "prh_test_gemm_tn_workspace_bytes", "prh_test_gemm_tn",
     "prh_profile_enable", "prh_profile_count", "prh_profile_reset", "prh_profile_read",
-    "prh_attn_forward", "prh_attn_backward",
+    "prh_attn_forward", "prh_attn_backward", "prh_attn_backward_ex",
     "prh_context_workspace_bytes", "prh_context_build",
     "prh_l1_loss_workspace_bytes", "prh_l1_loss", "prh_adam_step",
     "prh_add_dropout_layernorm_forward", "prh_add_dropout_layernorm_workspace_bytes",
@@ -107,7 +107,7 @@ def _bind(lib):
     lib.prh_linear_forward_ex.restype = i
     lib.prh_linear_forward_ex.argtypes = [vp, lg, vp, vp, vp, i, i, i, i, vp, vp, sz, i, vp]
     lib.prh_linear_backward_ex.restype = i
-    lib.prh_linear_backward_ex.argtypes = [vp, lg, vp, vp, vp, vp, vp, i, i, i, vp, vp, sz, i, vp]
+    lib.prh_linear_backward_ex.argtypes = [vp, lg, vp, vp, vp, vp, vp, i, i, i, vp, vp, vp, sz, i, vp]
     lib.prh_linear_forward_workspace_bytes.restype = sz
     lib.prh_linear_forward_workspace_bytes.argtypes = [i, i, i]
     lib.prh_linear_backward_workspace_bytes.restype = sz
@@ -147,6 +147,9 @@ def _bind(lib):
     lib.prh_adam_step.argtypes = [vp, vp, vp, vp, lg, f, f, f, f, f, i, i, vp]
     lib.prh_set_gemm_mode.restype = i
     lib.prh_set_gemm_mode.argtypes = [i]
+    lib.prh_attn_backward_ex.restype = i
+    lib.prh_attn_backward_ex.argtypes = [vp, lg, vp, lg, vp, lg, vp, lg, vp, vp, lg, vp, lg, vp, lg, vp, lg,
+                                         i, i, i, i, f, f, C.c_uint, vp, i, vp]
     lib.prh_set_dropout_seed_source.restype = i
     lib.prh_set_dropout_seed_source.argtypes = [vp]
     lib.prh_get_gemm_mode.restype = i

@@ -46,6 +46,9 @@ struct AttnParams {
   float keep_scale;              // 1/(1-p)
   unsigned drop_thresh;          // drop iff hash < thresh (0: no dropout)
   unsigned seed;
+  float* kv_amax_part;        // backward, optional: [blocks*4][2] largest |dV|, |dK| a wave stored (an
+                              // upper bound of the final values when M > 32 accumulates) - the
+                              // operand maxima of the K/V projection's backward GEMMs, for free
   const unsigned* seed_src;   // optional device word mixed into the seed (graph replays: a counter
                               // the caller advances on the device, so every replay draws new masks)
 };
@@ -189,6 +192,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnParams p) {
   float* scr = ktile + AT_TILE;
   const int col0 = h * 32;
   const unsigned bh = (unsigned)(b * p.H + h);
+  float mx_dv = 0.f, mx_dk = 0.f;
 
   for (int qt = 0; qt < p.M; qt += 32) {
     float qa[16], doa[16];
@@ -284,6 +288,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnParams p) {
               vv.x += old.x; vv.y += old.y; vv.z += old.z; vv.w += old.w;
             }
             *reinterpret_cast<float4*>(gp) = vv;
+            const float m4 = fmaxf(fmaxf(fabsf(vv.x), fabsf(vv.y)), fmaxf(fabsf(vv.z), fabsf(vv.w)));
+            if (pass == 0) mx_dv = fmaxf(mx_dv, m4); else mx_dk = fmaxf(mx_dk, m4);
           }
         }
       }
@@ -313,6 +319,17 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnParams p) {
       float* dqp = p.dq + (size_t)((long)b * p.M + qcol) * p.lddq + col0;
 #pragma unroll
       for (int r = 0; r < 16; ++r) dqp[crow(r, h2)] = dqacc[r] * p.scale;
+    }
+  }
+  if (p.kv_amax_part != nullptr) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mx_dv = fmaxf(mx_dv, __shfl_xor(mx_dv, o));
+      mx_dk = fmaxf(mx_dk, __shfl_xor(mx_dk, o));
+    }
+    if (lane == 0) {
+      p.kv_amax_part[(size_t)(blockIdx.x * 4 + wave) * 2] = mx_dv;
+      p.kv_amax_part[(size_t)(blockIdx.x * 4 + wave) * 2 + 1] = mx_dk;
     }
   }
 }

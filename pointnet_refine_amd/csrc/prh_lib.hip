@@ -787,7 +787,8 @@ size_t prh_linear_backward_workspace_bytes(int rows, int k, int n) {
 
 int prh_linear_backward_ex(const float* x, long ldx, const float* w, const float* dy, float* dx,
                            float* dw, float* db, int rows, int k, int n, const float* x_amax,
-                           void* workspace, size_t workspace_bytes, int device, void* stream) {
+                           const float* dy_amax_in, void* workspace, size_t workspace_bytes, int device,
+                           void* stream) {
   if (!x || !w || !dy || rows < 0 || k <= 0 || n <= 0) return fail(PRH_ERR_ARG, "linear_backward: bad argument");
   if ((k & 3) || (n & 3)) return fail(PRH_ERR_ARG, "linear_backward: k=%d and n=%d must be multiples of 4", k, n);
   HIP_TRY(hipSetDevice(device));
@@ -797,12 +798,13 @@ int prh_linear_backward_ex(const float* x, long ldx, const float* w, const float
   linear_bwd_carve(a, lw, rows, k, n);
   if (!a.ok) return fail(PRH_ERR_WORKSPACE, "linear_backward: workspace too small (%zu bytes)", workspace_bytes);
   float *wT = lw.wT, *slab = lw.slab, *cslab = lw.cslab;
-  const float* dy_amax = nullptr;
+  const float* dy_amax = dy_amax_in;
   if (dx != nullptr) {
     TRY(transpose(w, n, k, wT, st));   // wT [k, n]
     NTParams p; memset(&p, 0, sizeof(p));
     p.A = dy; p.lda = n; p.W = wT; p.ldw = n; p.C = dx; p.ldc = k; p.M = rows; p.N = k; p.K = n;
     p.wprep = lw.wprep;
+    p.amaxA = dy_amax;
     TRY((launch_nt<PRO_NONE, EPI_BIAS>(p, st)));
     dy_amax = p.amaxA;       // measured once for both GEMMs (lives in the head of lw.wprep)
   }
@@ -818,8 +820,8 @@ int prh_linear_backward_ex(const float* x, long ldx, const float* w, const float
 int prh_linear_backward(const float* x, long ldx, const float* w, const float* dy, float* dx,
                         float* dw, float* db, int rows, int k, int n, void* workspace,
                         size_t workspace_bytes, int device, void* stream) {
-  return prh_linear_backward_ex(x, ldx, w, dy, dx, dw, db, rows, k, n, nullptr, workspace, workspace_bytes,
-                                device, stream);
+  return prh_linear_backward_ex(x, ldx, w, dy, dx, dw, db, rows, k, n, nullptr, nullptr, workspace,
+                                workspace_bytes, device, stream);
 }
 
 // ------------------------------------------------------------------ MLP stack (point_mlp)
@@ -1289,12 +1291,13 @@ int prh_attn_forward(const float* q, long ldq, const float* k, long ldk, const f
   return PRH_OK;
 }
 
-int prh_attn_backward(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
-                      const float* o, long ldo, const float* lse, const float* dout, long lddo,
-                      float* dq, long lddq, float* dk, long lddk, float* dv, long lddv, int B, int M,
-                      int N, int H, float scale, float dropout_p, unsigned seed, int device,
-                      void* stream) {
+int prh_attn_backward_ex(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
+                         const float* o, long ldo, const float* lse, const float* dout, long lddo,
+                         float* dq, long lddq, float* dk, long lddk, float* dv, long lddv, int B, int M,
+                         int N, int H, float scale, float dropout_p, unsigned seed, float* kv_amax_part,
+                         int device, void* stream) {
   AttnParams a; memset(&a, 0, sizeof(a));
+  a.kv_amax_part = kv_amax_part;
   a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.o = (float*)o; a.ldo = ldo;
   a.lse = (float*)lse; a.dout = dout; a.lddo = lddo; a.dq = dq; a.lddq = lddq; a.dk = dk; a.lddk = lddk;
   a.dv = dv; a.lddv = lddv;
@@ -1317,6 +1320,14 @@ int prh_attn_backward(const float* q, long ldq, const float* k, long ldk, const 
   hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(B * (H / 4))), dim3(256), lds, st, a);
   LAUNCH_CHECK();
   return PRH_OK;
+}
+int prh_attn_backward(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
+                      const float* o, long ldo, const float* lse, const float* dout, long lddo,
+                      float* dq, long lddq, float* dk, long lddk, float* dv, long lddv, int B, int M,
+                      int N, int H, float scale, float dropout_p, unsigned seed, int device,
+                      void* stream) {
+  return prh_attn_backward_ex(q, ldq, k, ldk, v, ldv, o, ldo, lse, dout, lddo, dq, lddq, dk, lddk, dv, lddv, B, M, N,
+                              H, scale, dropout_p, seed, nullptr, device, stream);
 }
 
 // ------------------------------------------------------------------ profiler

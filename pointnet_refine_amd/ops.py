@@ -103,8 +103,11 @@ class LinearFn(torch.autograd.Function):
         if n % 4:
             raise RuntimeError("pointnet_refine_amd.linear backward: out_features must be a multiple of 4")
         dy2 = dy.reshape(rows, n)
+        hint = _DY_AMAX.pop(dy.data_ptr(), None) if _DY_AMAX else None
+        dy_amax = hint[0] if (hint is not None and hint[1] == tuple(dy.shape) and dy2.data_ptr() == dy.data_ptr()) else None
         if ctx.relu:
             dy2 = torch.where(y > 0, dy2, torch.zeros((), dtype=dy2.dtype, device=dy2.device))
+            dy_amax = None
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         dev = x2.device
@@ -115,7 +118,8 @@ class LinearFn(torch.autograd.Function):
         nb = L.lib().prh_linear_backward_workspace_bytes(rows, k, n)
         ws = _ws(dev, nb)
         L.check(L.lib().prh_linear_backward_ex(_p(x2), k, _p(w), _p(dy2), _p(dx), _p(dw), _p(db), rows,
-                                               k, n, _p(ctx.x_amax), _p(ws), ws.numel(), dev.index, _stream(dev)),
+                                               k, n, _p(ctx.x_amax), _p(dy_amax), _p(ws), ws.numel(), dev.index,
+                                               _stream(dev)),
                 "prh_linear_backward")
         return (dx.reshape(ctx.xshape) if need_dx else None), dw, db, None, None
 
@@ -359,6 +363,12 @@ def _rows_view(t: torch.Tensor, name: str):
     return t, t.stride(1)
 
 
+# gradient tensor address -> (1-element bound of its largest magnitude, shape): filled by the
+# producer of a gradient that knows the bound (the attention backward), consumed once by
+# LinearFn.backward
+_DY_AMAX = {}
+
+
 class GradArena:
     """Gradient buffers of the batched K/V projections, filled block by block by the
     attention backward of each decoder layer (no per-layer dK/dV tensors, no concatenation)."""
@@ -367,6 +377,7 @@ class GradArena:
         self.dk = None
         self.dv = None
         self.written = set()
+        self.part = None          # [n_blocks][waves][2]: largest |dV|, |dK| each attention backward stored
 
 
 class KVTokenFn(torch.autograd.Function):
@@ -393,7 +404,14 @@ class KVTokenFn(torch.autograd.Function):
                     a.dk[..., i * ctx.block:(i + 1) * ctx.block].zero_()
                     a.dv[..., i * ctx.block:(i + 1) * ctx.block].zero_()
         dk, dv = a.dk, a.dv
-        a.dk = a.dv = None
+        if a.part is not None:
+            # bounds of max|dV|, max|dK| for the K/V projections' backward GEMMs: picked up by
+            # LinearFn.backward through the gradient tensors' addresses (one reduction of the
+            # per-wave maxima instead of a read pass over each gradient buffer)
+            mx = a.part.amax(dim=(0, 1))
+            _DY_AMAX[dv.data_ptr()] = (mx[0:1], tuple(dv.shape))
+            _DY_AMAX[dk.data_ptr()] = (mx[1:2], tuple(dk.shape))
+        a.dk = a.dv = a.part = None
         a.written = set()
         return dk, dv, None, None
 
@@ -454,15 +472,20 @@ class AttentionFn(torch.autograd.Function):
             dkp = C.c_void_p(dk.data_ptr() + 4 * koff)
             dvp = C.c_void_p(dv.data_ptr() + 4 * voff)
             a.written.add(ctx.block)
+            nblk, waves = k.shape[2] // Cq, B * (heads // 4) * 4
+            if a.part is None:
+                a.part = torch.zeros((nblk, waves, 2), dtype=torch.float32, device=q.device)
+            partp = C.c_void_p(a.part.data_ptr() + 4 * ctx.block * waves * 2)
         else:
             dk = torch.empty((B, N, Cq), dtype=torch.float32, device=q.device)
             dv = torch.empty((B, N, Cq), dtype=torch.float32, device=q.device)
             lddk, dkp, dvp = Cq, _p(dk), _p(dv)
+            partp = None
         kp = C.c_void_p(k.data_ptr() + 4 * koff)
         vp = C.c_void_p(v.data_ptr() + 4 * voff)
-        L.check(L.lib().prh_attn_backward(_p(q), Cq, kp, ldk, vp, ldv, _p(o), Cq, _p(lse), _p(do), Cq,
-                                          _p(dq), Cq, dkp, lddk, dvp, lddk, B, M, N, heads, scale,
-                                          dropout_p, seed, q.device.index, _stream(q.device)),
+        L.check(L.lib().prh_attn_backward_ex(_p(q), Cq, kp, ldk, vp, ldv, _p(o), Cq, _p(lse), _p(do), Cq,
+                                             _p(dq), Cq, dkp, lddk, dvp, lddk, B, M, N, heads, scale,
+                                             dropout_p, seed, partp, q.device.index, _stream(q.device)),
                 "prh_attn_backward")
         if a is not None:
             return dq, None, None, None, None, None, torch.zeros((), device=q.device), None, None
