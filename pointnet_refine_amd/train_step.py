@@ -145,7 +145,7 @@ class TrainStep:
         self.model = model
         self.loss_fn = loss_fn if loss_fn is not None else deep_supervision_l1
         self.geometry = None
-        self.use_graph, self._graph, self._static = bool(graph), None, None
+        self.use_graph, self._graph, self._static, self._seed = bool(graph), None, None, None
         self.chunk = decoder_chunk
         self.world, self.group = world_size, group
         self.grads = FlatGrads(model.parameters())
@@ -191,6 +191,20 @@ class TrainStep:
             del out, loss_c, mem_c, tgt_c
         torch.autograd.backward([memory, tgt0], [d_memory, d_tgt0])
         return total
+
+    def close(self):
+        """Unregister the device seed counter of a graph-captured step (the library keeps the
+        pointer it was given; call this - or drop the TrainStep - before freeing GPU memory)."""
+        if getattr(self, "_seed", None) is not None:
+            try:
+                from . import _lib as L
+                L.lib().prh_set_dropout_seed_source(None)
+            except Exception:
+                pass
+            self._seed = None
+
+    def __del__(self):
+        self.close()
 
     def _capture(self, context, noisy_line, target):
         """Warm up on a side stream, then capture zero-grad + forward + loss + backward."""
