@@ -34,7 +34,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0     # dense v_mfma_f32_32x32x16_bf16
 SPLIT_PRODUCTS = 6                 # bf16 MFMA products per fp32-accurate MAC on the split cores
 SPLIT16_PRODUCTS = 3               # fp16 MFMA products per fp32-accurate MAC on the split-fp16 cores
 DEFAULT_GEMM = "split16"
-PMC_TRAFFIC_FILE = "r01j_pmc_traffic_B4096.json"
+PMC_TRAFFIC_FILE = "r01p_pmc_traffic_B4096.json"
 HBM_PEAK_GBS = 8000.0
 
 
@@ -83,6 +83,7 @@ def parse():
                     help="capture forward+loss+backward in a HIP graph (small, launch-bound batches)")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of the fused flat-buffer Adam")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernels", type=int, default=0, help="print the K longest GEMM launches (live HIP-event times) to stderr")
     ap.add_argument("--cpu-batch", type=int, default=16)
     return ap.parse_args()
 
@@ -207,6 +208,9 @@ def main():
         a[1] += ms.value
     lib.prh_profile_enable(0)
     hip_ms = sum(a[1] for a in agg.values())
+    if rank == 0 and args.kernels > 0:
+        for k, (c, t, f, _) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:args.kernels]:
+            print(f"[bench] {k:44s} x{c:3d} {t / c:8.3f} ms  {f / (t / c * 1e-3) / 1e12:7.1f} TF", file=sys.stderr)
     dom = max(agg.items(), key=lambda kv: kv[1][1])
     dname, (cnt, tot_ms, flops, bytes_) = dom
     avg_ms = tot_ms / cnt

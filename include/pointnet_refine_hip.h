@@ -272,6 +272,11 @@ size_t prh_test_gemm_tn_workspace_bytes(int p, int mo, int ni);
 int prh_test_gemm_tn(const float* a, const float* b, float* c, float* colsum, int p, int mo,
                      int ni, void* workspace, size_t workspace_bytes, int device, void* stream);
 
+/* Diagnostic: which XCD (XCC_ID) and CU (HW_ID) each workgroup of a `blocks` x 512-thread
+ * launch with `lds_bytes` of dynamic LDS lands on; out[2*b] = XCC_ID, out[2*b+1] = HW_ID.
+ * The GEMM kernels assume workgroup b runs on XCD b % 8 (xcd_remap); this checks it. */
+int prh_test_xcc_map(int blocks, int lds_bytes, int* out, int device, void* stream);
+
 /* Optional launch profiler used by bench.py: when enabled (capacity > 0) every GEMM launch is
  * bracketed by HIP events on the launch stream; prh_profile_read returns its duration and
  * the algorithmic FLOPs / bytes of that launch.  capacity 0 disables and frees the events. */

@@ -54,7 +54,7 @@ EXPORTS = [
     "prh_linear_forward_workspace_bytes", "prh_linear_forward", "prh_linear_forward_ex",
     "prh_linear_backward_workspace_bytes", "prh_linear_backward", "prh_linear_backward_ex",
     "prh_mlp_stack_workspace_bytes", "prh_mlp_stack_forward", "prh_mlp_stack_backward",
-    "prh_test_gemm_nt", "prh_test_gemm_tn_workspace_bytes", "prh_test_gemm_tn",
+    "prh_test_gemm_nt", "prh_test_gemm_tn_workspace_bytes", "prh_test_gemm_tn", "prh_test_xcc_map",
     "prh_profile_enable", "prh_profile_count", "prh_profile_reset", "prh_profile_read",
     "prh_attn_forward", "prh_attn_backward", "prh_attn_backward_ex",
     "prh_context_workspace_bytes", "prh_context_build",
@@ -166,6 +166,8 @@ def _bind(lib):
     lib.prh_test_gemm_tn_workspace_bytes.argtypes = [i, i, i]
     lib.prh_test_gemm_tn.restype = i
     lib.prh_test_gemm_tn.argtypes = [vp, vp, vp, vp, i, i, i, vp, sz, i, vp]
+    lib.prh_test_xcc_map.restype = i
+    lib.prh_test_xcc_map.argtypes = [i, i, vp, i, vp]
     return lib
 
 

@@ -468,6 +468,11 @@ __device__ __forceinline__ void nt_epilogue_vec(ACC& acc, const NTParams& p, int
       }
       if (ok) *reinterpret_cast<float4*>(Cb + lr * ldc + col4) = v;
     }
+    // keep the running column sums here: left alone, the compiler sinks all 64 accumulation
+    // steps into the F_STATS branch below and carries every v and z there (32 spilled VGPRs,
+    // 9 GB of scratch writes per fusion-dgrad launch at B=4096)
+    if (EPI == EPI_DGRAD)
+      asm volatile("" : "+v"(s1.x), "+v"(s1.y), "+v"(s1.z), "+v"(s1.w), "+v"(s2.x), "+v"(s2.y), "+v"(s2.z), "+v"(s2.w));
     }
   }
   if (EPI == EPI_DGRAD && (p.flags & F_STATS) != 0) {
@@ -597,6 +602,7 @@ struct TNParams {
   int tiles_m, tiles_n;
   const float* amaxA;            // fp16-plane core: largest |proA(A)|, |proB(B)| (device; null:
   const float* amaxB;            //   the launch measures them)
+  int* pace;                     // transposed-read core: per-split progress counters (zeroed), or null
 };
 
 template <int PROA, int PROB>

@@ -287,6 +287,18 @@ __device__ __forceinline__ f16x8 tr_fragment(const char* plane, int col0, int la
   return __builtin_bit_cast(f16x8, pr);
 }
 
+// Pacing.  The tiles of one split run together on one XCD (xcd_remap) and share the split's
+// rows of A and B through its 4 MB L2 - but only while they stay within ~340 rows of each
+// other.  Nothing holds them there, and the launch is bistable: in step, the fusion wgrad at
+// B=4096 fetches 52 GB for 50.5 GB of operands and takes 45 ms; once the tiles have drifted
+// apart the misses keep them apart, and the same launch fetches 160-170 GB and takes 49 ms
+// (both seen, box to box, with rocprofv3 --pmc FETCH_SIZE).  So every TR_PACE k-tiles thread
+// 0 publishes the block's progress and, when the block is more than one unit ahead of its
+// split's mean, sleeps until the others catch up (the other waves wait at the next barrier).
+// The wait is bounded and abandoned for good after one time-out: blocks that are not
+// co-resident cost a fraction of a millisecond once, never a hang.
+constexpr int TR_PACE = 8;            // k-tiles (128 rows) between progress reports
+constexpr int TR_PACE_SPINS = 256;    // x (s_sleep 16 + one L2 load): ~0.3 ms at most, once
 template <int PROB>
 __global__ __launch_bounds__(512, 2) void gemm_tn_tr_kernel(const TNParams p) {
   static_assert(PROB == PRO_NONE || PROB == PRO_BNRELU, "prologue not supported");
@@ -412,8 +424,21 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_tr_kernel(const TNParams p) {
     }
     __syncthreads();
   };
+  const int pace_tiles = p.tiles_m * p.tiles_n;
+  bool pacing = p.pace != nullptr && tid == 0;
   int kt = 0;
   for (; kt + 1 < KT; kt += 2) {
+    if ((kt & (TR_PACE - 1)) == 0 && pacing) {
+      const int mine = (kt / TR_PACE + 1) * pace_tiles;
+      int tot = __hip_atomic_fetch_add(p.pace + split, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+      int spins = 0;
+      while (mine - tot > pace_tiles && spins < TR_PACE_SPINS) {
+        __builtin_amdgcn_s_sleep(16);
+        tot = __hip_atomic_load(p.pace + split, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ++spins;
+      }
+      if (spins == TR_PACE_SPINS) pacing = false;
+    }
     iter(kt, std::integral_constant<int, 1>{});
     iter(kt + 1, std::integral_constant<int, 0>{});
   }

@@ -680,4 +680,15 @@ __global__ __launch_bounds__(256) void ln_param_grad_kernel(const float* __restr
   }
 }
 
+// diagnostic behind prh_test_xcc_map: where the dispatcher put each workgroup
+__global__ __launch_bounds__(512) void xcc_probe_kernel(int* out) {
+  extern __shared__ char probe_lds[];
+  if (threadIdx.x == 0) {
+    probe_lds[0] = 0;
+    out[2 * blockIdx.x] = (int)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));      // XCC_ID[3:0]
+    out[2 * blockIdx.x + 1] = (int)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));  // HW_ID
+  }
+  for (int i = 0; i < 400; ++i) __builtin_amdgcn_s_sleep(64);   // stay resident ~0.1 ms
+}
+
 }  // namespace prh

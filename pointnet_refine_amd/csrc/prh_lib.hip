@@ -122,6 +122,7 @@ inline int gemm_mode() {
 // PRH_H2_GEN=1 keeps the split-fp16 NT GEMMs on the first-generation core (32x32x16 MFMA, BK 16)
 bool g_h2_gen2 = [] { const char* e = getenv("PRH_H2_GEN"); return !(e && strcmp(e, "1") == 0); }();
 // PRH_TN_TR=0 keeps the split-fp16 wgrads on the column-staged core
+bool g_tn_pace = [] { const char* e = getenv("PRH_TN_PACE"); return !(e && strcmp(e, "0") == 0); }();
 bool g_tn_tr = [] { const char* e = getenv("PRH_TN_TR"); return !(e && strcmp(e, "0") == 0); }();
 inline const char* core_tag() { return gemm_mode() == 2 ? "b1" : (gemm_mode() == 3 ? "h2" : "s3"); }
 
@@ -370,6 +371,16 @@ int launch_tn(TNParams& p, float* slab, float* colsum_slab, float* C, long ldc, 
         bool tr = false;
         if constexpr (PROA == PRO_NONE && (PROB == PRO_NONE || PROB == PRO_BNRELU))
           tr = mode == 3 && g_tn_tr && ((p.Mo | p.Ni | (int)p.lda | (int)p.ldb) & 3) == 0;
+        p.pace = nullptr;
+        // (only where many tiles share long splits: with 6 tiles per split the waits cost the
+        // attention K/V wgrad 7 % and there is little to share)
+        if (tr && g_tn_pace && pl.tiles_m * pl.tiles_n >= 8 && pl.splits <= ABSMAX_MAX_BLOCKS &&
+            pl.rows_per_split >= 16384) {
+          // progress counters live where the (already consumed) per-block maxima were
+          p.pace = reinterpret_cast<int*>(slab + (size_t)pl.splits * p.Mo * p.Ni + 64);
+          if (hipMemsetAsync(p.pace, 0, sizeof(int) * pl.splits, st) != hipSuccess)
+            return fail(PRH_ERR_HIP, "gemm_tn: memset of the pacing counters failed");
+        }
         snprintf(nm, sizeof(nm), "gemm_tn_%s<%d,%d> Mo=%d Ni=%d", tr ? "h2tr" : core_tag(), PROA, PROB, p.Mo, p.Ni);
         ProfScope ps(nm, 2.0 * p.P * (double)p.Mo * p.Ni, by, st);
         if constexpr (PROA == PRO_NONE && (PROB == PRO_NONE || PROB == PRO_BNRELU)) {
@@ -1375,6 +1386,17 @@ int prh_test_gemm_nt(const float* a, const float* w, float* c, int m, int n, int
   if (workspace != nullptr && workspace_bytes >= s3_weight_bytes(n, k) + 256)
     p.wprep = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   return launch_nt<PRO_NONE, EPI_BIAS>(p, (hipStream_t)stream);
+}
+int prh_test_xcc_map(int blocks, int lds_bytes, int* out, int device, void* stream) {
+  HIP_TRY(hipSetDevice(device));
+  if (blocks <= 0 || lds_bytes < 0 || lds_bytes > 160 * 1024 || out == nullptr)
+    return fail(PRH_ERR_ARG, "test_xcc_map: bad arguments");
+  static const int attr_rc = allow_big_lds(xcc_probe_kernel);
+  if (attr_rc != PRH_OK) return attr_rc;
+  hipLaunchKernelGGL(xcc_probe_kernel, dim3((unsigned)blocks), dim3(512), (size_t)lds_bytes,
+                     (hipStream_t)stream, out);
+  LAUNCH_CHECK();
+  return PRH_OK;
 }
 size_t prh_test_gemm_tn_workspace_bytes(int p, int mo, int ni) {
   Arena a;
