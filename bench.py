@@ -34,7 +34,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0     # dense v_mfma_f32_32x32x16_bf16
 SPLIT_PRODUCTS = 6                 # bf16 MFMA products per fp32-accurate MAC on the split cores
 SPLIT16_PRODUCTS = 3               # fp16 MFMA products per fp32-accurate MAC on the split-fp16 cores
 DEFAULT_GEMM = "split16"
-PMC_TRAFFIC_FILE = "r01p_pmc_traffic_B4096.json"
+PMC_TRAFFIC_FILE = "r01q_pmc_traffic_B4096.json"
 HBM_PEAK_GBS = 8000.0
 
 
