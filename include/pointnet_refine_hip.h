@@ -131,6 +131,26 @@ int prh_linear_forward_ex(const float* x, long ldx, const float* w, const float*
                           int rows, int k, int n, int relu, const float* x_amax, void* workspace,
                           size_t workspace_bytes, int device, void* stream);
 
+/* Same plus a residual input added in the GEMM epilogue: y = act(x W^T + b + resid), resid
+ * [rows,n] (ld ldres) - e.g. k-input = memory + pos_emb(xyz) (src/model.py:123-126) with the
+ * addition riding on the second Linear of the positional-encoding MLP. */
+int prh_linear_forward_res(const float* x, long ldx, const float* w, const float* b, const float* resid,
+                           long ldres, float* y, int rows, int k, int n, int relu, const float* x_amax,
+                           void* workspace, size_t workspace_bytes, int device, void* stream);
+
+/* First layer of the positional-encoding MLP (src/model.py:64-75, nn.Linear(3, hidden) + ReLU)
+ * as one elementwise pass: h[r,c] = relu(b0[c] + sum_j xyz[r*ld + j] w0[c*3 + j]), j < 3.
+ * xyz rows are read in place with leading dimension ld >= 3 (ld = C for (B,N,C) context rows);
+ * hidden: a power of two in [4, 1024].  backward: dw0 [hidden,3] and db0 [hidden] (either may be
+ * NULL) from dh [rows,hidden] masked by h > 0; no gradient for xyz (the reference's inputs carry
+ * none). */
+int prh_pos_hidden_forward(const float* xyz, long ld, const float* w0, const float* b0, float* h,
+                           long rows, int hidden, int device, void* stream);
+size_t prh_pos_hidden_backward_workspace_bytes(long rows, int hidden);
+int prh_pos_hidden_backward(const float* xyz, long ld, const float* h, const float* dh, float* dw0,
+                            float* db0, long rows, int hidden, void* workspace, size_t workspace_bytes,
+                            int device, void* stream);
+
 /* nn.Linear backward: dx = dy W (NULL = skip), dw = dy^T x, db = colsum(dy).
  * n and k multiples of 4. */
 size_t prh_linear_backward_workspace_bytes(int rows, int k, int n);

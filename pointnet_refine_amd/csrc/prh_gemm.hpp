@@ -40,6 +40,7 @@ enum {
   F_STATS = 8,        // EPI_DGRAD: write per-wave column sums of v and v*E1
   F_STORE_GATE = 16,  // EPI_GATE: also store m = 0.5+0.5*sigmoid() to C2
   F_E1_ROWVEC = 32,   // EPI_DGRAD: E1 is one value per row (E1[row*lde1]), not a matrix
+  F_RESID = 64,       // EPI_BIAS: C = acc + bias + E1 (residual input, before the optional ReLU)
 };
 
 struct NTParams {
@@ -137,6 +138,7 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[MT][NT], const NTParam
         for (int r = 0; r < 16; ++r) {
           const int lr = mt * 32 + crow(r, half);
           float v = acc[mt][nt][r] + bias;
+          if (EPI == EPI_BIAS && (p.flags & F_RESID) != 0 && lr < mrows && cok) v += Eb[lr * lde1 + col];
           if ((p.flags & F_RELU_OUT) != 0) v = fmaxf(v, 0.f);
           acc[mt][nt][r] = v;
           if (lr < mrows && cok) {
@@ -393,7 +395,8 @@ __device__ __forceinline__ void nt_epilogue_vec(ACC& acc, const NTParams& p, int
   if (EPI == EPI_BIAS_STATS) epi_col_stats(acc, p, cbase, mrows, rb, lane);
 
   const bool mask = (p.flags & F_MASK) != 0, accum = (p.flags & F_ACCUM) != 0;
-  const bool need_z = (EPI == EPI_DGRAD && (mask || (p.flags & F_STATS) != 0)) || EPI == EPI_GATE;
+  const bool resid = EPI == EPI_BIAS && (p.flags & F_RESID) != 0;
+  const bool need_z = (EPI == EPI_DGRAD && (mask || (p.flags & F_STATS) != 0)) || EPI == EPI_GATE || resid;
   float4 s1 = zero4(), s2 = zero4();
   // The epilogue operands (z for the ReLU mask / statistics / gate, the old C when
   // accumulating) are fetched in ONE batch per 32-row block, branch-free (rows and columns
@@ -472,8 +475,11 @@ __device__ __forceinline__ void nt_epilogue_vec(ACC& acc, const NTParams& p, int
         v.x = fmaxf(fmaf(z.x, es4.x, et4.x), 0.f) * m.x; v.y = fmaxf(fmaf(z.y, es4.y, et4.y), 0.f) * m.y;
         v.z = fmaxf(fmaf(z.z, es4.z, et4.z), 0.f) * m.z; v.w = fmaxf(fmaf(z.w, es4.w, et4.w), 0.f) * m.w;
         if (ok && (p.flags & F_STORE_GATE) != 0) *reinterpret_cast<float4*>(C2b + lr * ldc2 + col4) = m;
-      } else if ((p.flags & F_RELU_OUT) != 0) {
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      } else {
+        if (resid) { v.x += z.x; v.y += z.y; v.z += z.z; v.w += z.w; }
+        if ((p.flags & F_RELU_OUT) != 0) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
       }
       if (ok) *reinterpret_cast<float4*>(Cb + lr * ldc + col4) = v;
     }

@@ -680,6 +680,88 @@ __global__ __launch_bounds__(256) void ln_param_grad_kernel(const float* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// First layer of the positional-encoding MLP (src/model.py:64-75: Linear(3, H) + ReLU) as an
+// elementwise kernel: h[r, c] = relu(b0[c] + sum_j xyz[r*ld + j] * w0[c*3 + j]).  A 3-deep
+// "GEMM" is pure HBM work - 12 B read and 4*H B written per point - and the points are read
+// in place from the (B, N, C) context rows (ld = C), not from a sliced copy.
+// Thread -> 4 consecutive columns; the block covers 256 / (H/4) rows per pass.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pos_hidden_fwd_kernel(const float* __restrict__ xyz, long ld,
+                                                             const float* __restrict__ w0,
+                                                             const float* __restrict__ b0,
+                                                             float* __restrict__ h, long P, int H) {
+  const int cg = H >> 2, tc = threadIdx.x % cg, tr = threadIdx.x / cg, rpp = 256 / cg;
+  float w[4][3], b[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    b[c] = b0 != nullptr ? b0[4 * tc + c] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) w[c][j] = w0[(4 * tc + c) * 3 + j];
+  }
+  for (long r = (long)blockIdx.x * rpp + tr; r < P; r += (long)gridDim.x * rpp) {
+    const float x0 = xyz[r * ld], x1 = xyz[r * ld + 1], x2 = xyz[r * ld + 2];
+    float4 o;
+    o.x = fmaxf(fmaf(x2, w[0][2], fmaf(x1, w[0][1], fmaf(x0, w[0][0], b[0]))), 0.f);
+    o.y = fmaxf(fmaf(x2, w[1][2], fmaf(x1, w[1][1], fmaf(x0, w[1][0], b[1]))), 0.f);
+    o.z = fmaxf(fmaf(x2, w[2][2], fmaf(x1, w[2][1], fmaf(x0, w[2][0], b[2]))), 0.f);
+    o.w = fmaxf(fmaf(x2, w[3][2], fmaf(x1, w[3][1], fmaf(x0, w[3][0], b[3]))), 0.f);
+    *reinterpret_cast<float4*>(h + r * H + 4 * tc) = o;
+  }
+}
+
+// Its backward: dz = dh * (h > 0); part[block][c*4 + j] = sum_r dz[r,c] * xyz[r,j] (j < 3) and
+// sum_r dz[r,c] (j == 3) over the block's rows.  pos_hidden_final_kernel adds the blocks up
+// (two stages, no atomics: the result does not depend on the launch order).
+__global__ __launch_bounds__(256) void pos_hidden_bwd_kernel(const float* __restrict__ xyz, long ld,
+                                                             const float* __restrict__ h,
+                                                             const float* __restrict__ dh,
+                                                             float* __restrict__ part, long P, int H) {
+  __shared__ float red[256 * 17];
+  const int cg = H >> 2, tc = threadIdx.x % cg, tr = threadIdx.x / cg, rpp = 256 / cg;
+  float a[4][4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[c][j] = 0.f;
+  for (long r = (long)blockIdx.x * rpp + tr; r < P; r += (long)gridDim.x * rpp) {
+    const float x0 = xyz[r * ld], x1 = xyz[r * ld + 1], x2 = xyz[r * ld + 2];
+    const float4 hv = *reinterpret_cast<const float4*>(h + r * H + 4 * tc);
+    const float4 g = *reinterpret_cast<const float4*>(dh + r * H + 4 * tc);
+    const float dz[4] = {hv.x > 0.f ? g.x : 0.f, hv.y > 0.f ? g.y : 0.f, hv.z > 0.f ? g.z : 0.f,
+                         hv.w > 0.f ? g.w : 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      a[c][0] = fmaf(dz[c], x0, a[c][0]); a[c][1] = fmaf(dz[c], x1, a[c][1]);
+      a[c][2] = fmaf(dz[c], x2, a[c][2]); a[c][3] += dz[c];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[threadIdx.x * 17 + c * 4 + j] = a[c][j];
+  __syncthreads();
+  // thread t < 4*H sums element t (= column*4 + j) over the rpp row groups
+  for (int e = threadIdx.x; e < 4 * H; e += 256) {
+    const int col = e >> 2, j = e & 3, tcc = col >> 2, c = col & 3;
+    float s = 0.f;
+    for (int g = 0; g < rpp; ++g) s += red[(g * cg + tcc) * 17 + c * 4 + j];
+    part[(size_t)blockIdx.x * 4 * H + e] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void pos_hidden_final_kernel(const float* __restrict__ part, int nblk,
+                                                               int H, float* __restrict__ dw0,
+                                                               float* __restrict__ db0) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= 4 * H) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += part[(size_t)b * 4 * H + e];
+  const int col = e >> 2, j = e & 3;
+  if (j < 3) { if (dw0 != nullptr) dw0[col * 3 + j] = s; }
+  else if (db0 != nullptr) db0[col] = s;
+}
+
 // diagnostic behind prh_test_xcc_map: where the dispatcher put each workgroup
 __global__ __launch_bounds__(512) void xcc_probe_kernel(int* out) {
   extern __shared__ char probe_lds[];

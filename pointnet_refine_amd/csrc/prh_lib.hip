@@ -783,11 +783,73 @@ int prh_linear_forward_ex(const float* x, long ldx, const float* w, const float*
   p.amaxA = x_amax;
   return launch_nt<PRO_NONE, EPI_BIAS>(p, (hipStream_t)stream);
 }
+int prh_linear_forward_res(const float* x, long ldx, const float* w, const float* b, const float* resid,
+                           long ldres, float* y, int rows, int k, int n, int relu, const float* x_amax,
+                           void* workspace, size_t workspace_bytes, int device, void* stream) {
+  if (!x || !w || !y || !resid || rows < 0 || k <= 0 || n <= 0 || ldres < n)
+    return fail(PRH_ERR_ARG, "linear_forward_res: bad argument");
+  HIP_TRY(hipSetDevice(device));
+  NTParams p; memset(&p, 0, sizeof(p));
+  p.A = x; p.lda = ldx; p.W = w; p.ldw = k; p.C = y; p.ldc = n;
+  p.M = rows; p.N = n; p.K = k; p.bias = b; p.flags = (relu ? F_RELU_OUT : 0) | F_RESID;
+  p.E1 = resid; p.lde1 = ldres;
+  if (workspace != nullptr && workspace_bytes >= s3_weight_bytes(n, k) + 256)
+    p.wprep = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  p.amaxA = x_amax;
+  return launch_nt<PRO_NONE, EPI_BIAS>(p, (hipStream_t)stream);
+}
 int prh_linear_forward(const float* x, long ldx, const float* w, const float* b, float* y,
                        int rows, int k, int n, int relu, void* workspace, size_t workspace_bytes,
                        int device, void* stream) {
   return prh_linear_forward_ex(x, ldx, w, b, y, rows, k, n, relu, nullptr, workspace, workspace_bytes, device,
                                stream);
+}
+
+// ---- positional-encoding MLP, first layer (src/model.py:64-75) -------------------------
+static int pos_hidden_blocks(long P, int H) {
+  const long rpp = 256 / (H / 4);
+  long nb = (P + rpp * 16 - 1) / (rpp * 16);
+  return (int)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb));
+}
+static bool pos_hidden_ok(int H) { return H >= 4 && H <= 1024 && (H & (H - 1)) == 0; }
+int prh_pos_hidden_forward(const float* xyz, long ld, const float* w0, const float* b0, float* h,
+                           long rows, int hidden, int device, void* stream) {
+  if (!xyz || !w0 || !h || rows < 0 || ld < 3) return fail(PRH_ERR_ARG, "pos_hidden_forward: bad argument");
+  if (!pos_hidden_ok(hidden))
+    return fail(PRH_ERR_ARG, "pos_hidden_forward: hidden=%d must be a power of two in [4, 1024]", hidden);
+  HIP_TRY(hipSetDevice(device));
+  if (rows == 0) return PRH_OK;
+  const long rpp = 256 / (hidden / 4);
+  long nb = (rows + rpp * 4 - 1) / (rpp * 4);
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(pos_hidden_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, xyz, ld,
+                     w0, b0, h, rows, hidden);
+  LAUNCH_CHECK();
+  return PRH_OK;
+}
+size_t prh_pos_hidden_backward_workspace_bytes(long rows, int hidden) {
+  if (!pos_hidden_ok(hidden)) return 0;
+  return (size_t)pos_hidden_blocks(rows, hidden) * 4 * hidden * sizeof(float) + 256;
+}
+int prh_pos_hidden_backward(const float* xyz, long ld, const float* h, const float* dh, float* dw0,
+                            float* db0, long rows, int hidden, void* workspace, size_t workspace_bytes,
+                            int device, void* stream) {
+  if (!xyz || !h || !dh || rows < 0 || ld < 3) return fail(PRH_ERR_ARG, "pos_hidden_backward: bad argument");
+  if (!pos_hidden_ok(hidden))
+    return fail(PRH_ERR_ARG, "pos_hidden_backward: hidden=%d must be a power of two in [4, 1024]", hidden);
+  HIP_TRY(hipSetDevice(device));
+  Arena a(workspace, workspace_bytes);
+  const int nb = pos_hidden_blocks(rows, hidden);
+  float* part = a.f((size_t)nb * 4 * hidden);
+  if (!a.ok) return fail(PRH_ERR_WORKSPACE, "pos_hidden_backward: workspace too small (%zu bytes)", workspace_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(pos_hidden_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, st, xyz, ld, h, dh, part,
+                     rows, hidden);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(pos_hidden_final_kernel, dim3((unsigned)cdiv(4 * hidden, 256)), dim3(256), 0, st,
+                     (const float*)part, nb, hidden, dw0, db0);
+  LAUNCH_CHECK();
+  return PRH_OK;
 }
 
 size_t prh_linear_backward_workspace_bytes(int rows, int k, int n) {

@@ -120,10 +120,19 @@ class PositionalEncoding(nn.Module):
         super().__init__()
         self.mlp = nn.Sequential(nn.Linear(in_dim, out_dim), nn.ReLU(), nn.Linear(out_dim, out_dim))
 
-    def forward(self, xyz):
-        # Linear(3,256) stays on torch (3-wide input); Linear(256,256) runs on the HIP cores
-        h = F.relu(F.linear(xyz, self.mlp[0].weight, self.mlp[0].bias))
-        return _lin(h, self.mlp[2].weight, self.mlp[2].bias)
+    def forward(self, xyz, resid=None):
+        """resid: optional tensor added to the encoding (the decoder's k-input memory + pos,
+        src/model.py:123-126) - on the GPU it rides on the second Linear's epilogue."""
+        l0, l2 = self.mlp[0], self.mlp[2]
+        if (xyz.is_cuda and xyz.dtype == torch.float32 and l0.in_features == 3 and not xyz.requires_grad
+                and ops.pos_hidden_supported(l0.out_features) and l2.out_features % 4 == 0):
+            # Linear(3,H)+ReLU: one elementwise HIP pass over the points in place (a 3-deep GEMM
+            # is HBM work); Linear(H,H) (+ resid) on the HIP GEMM cores
+            h = ops.pos_hidden(xyz, l0.weight, l0.bias)
+            return ops.linear(h, l2.weight, l2.bias, None, False, resid)
+        h = F.relu(F.linear(xyz, l0.weight, l0.bias))
+        y = _lin(h, l2.weight, l2.bias)
+        return y if resid is None else y + resid
 
 
 class DetrTransformerDecoderLayer(nn.Module):
@@ -245,10 +254,9 @@ class LineRefineNet(nn.Module):
         and value projections of ALL layers (src/model.py:123-126: k = memory+pos, v = memory,
         packed in_proj rows [256:512] and [512:768]) are two GEMMs of width 6*256 on the HIP
         GEMM cores instead of twelve library GEMMs plus six elementwise adds."""
-        pos_mem = self.pos_emb(context[:, :, :3])                   # (B, N, 256)
         d = self.d_model
         layers = self.decoder_layers
-        mempos = memory + pos_mem
+        mempos = self.pos_emb(context[:, :, :3], resid=memory)      # memory + pos_mem, (B, N, 256)
         wk = torch.cat([l.cross_attn.in_proj_weight[d:2 * d] for l in layers])
         bk = torch.cat([l.cross_attn.in_proj_bias[d:2 * d] for l in layers])
         wv = torch.cat([l.cross_attn.in_proj_weight[2 * d:] for l in layers])

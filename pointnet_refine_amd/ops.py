@@ -61,10 +61,11 @@ class LinearFn(torch.autograd.Function):
     """y = x W^T + b on the fp32 MFMA GEMM core (context_proj, src/model.py:147,194)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, x_amax=None, relu=False):
+    def forward(ctx, x, w, b, x_amax=None, relu=False, resid=None):
         """x_amax: optional 1-element device tensor >= max|x| (saves the read pass that places the
         operand for the split-fp16 core; e.g. the encoder's bound for its output).  relu: apply
-        ReLU in the GEMM epilogue (the backward masks dy with y > 0)."""
+        ReLU in the GEMM epilogue (the backward masks dy with y > 0).  resid: tensor of the output's
+        shape added in the epilogue, y = act(x W^T + b + resid)."""
         _req_gpu_f32(x, "input")
         _req_gpu_f32(w, "weight")
         n, k = w.shape
@@ -79,9 +80,22 @@ class LinearFn(torch.autograd.Function):
         rows = x2.shape[0]
         y = torch.empty((rows, n), dtype=torch.float32, device=x.device)
         ws = _ws(x.device, L.lib().prh_linear_forward_workspace_bytes(rows, k, n))
-        L.check(L.lib().prh_linear_forward_ex(_p(x2), k, _p(w), _p(b), _p(y), rows, k, n, int(bool(relu)), _p(x_amax), _p(ws),
-                                              ws.numel(), x.device.index, _stream(x.device)),
-                "prh_linear_forward")
+        if resid is not None:
+            _req_gpu_f32(resid, "residual")
+            if tuple(resid.shape) != (*x.shape[:-1], n):
+                raise RuntimeError(f"residual shape {tuple(resid.shape)} does not match the output {(*x.shape[:-1], n)}")
+            r2 = resid.reshape(rows, n)
+            if not r2.is_contiguous():
+                r2 = r2.contiguous()
+            L.check(L.lib().prh_linear_forward_res(_p(x2), k, _p(w), _p(b), _p(r2), n, _p(y), rows, k, n,
+                                                   int(bool(relu)), _p(x_amax), _p(ws), ws.numel(),
+                                                   x.device.index, _stream(x.device)),
+                    "prh_linear_forward_res")
+        else:
+            L.check(L.lib().prh_linear_forward_ex(_p(x2), k, _p(w), _p(b), _p(y), rows, k, n, int(bool(relu)), _p(x_amax), _p(ws),
+                                                  ws.numel(), x.device.index, _stream(x.device)),
+                    "prh_linear_forward")
+        ctx.has_resid = resid is not None
         if relu:
             ctx.save_for_backward(x2, w, y)
         else:
@@ -121,11 +135,71 @@ class LinearFn(torch.autograd.Function):
                                                k, n, _p(ctx.x_amax), _p(dy_amax), _p(ws), ws.numel(), dev.index,
                                                _stream(dev)),
                 "prh_linear_backward")
-        return (dx.reshape(ctx.xshape) if need_dx else None), dw, db, None, None
+        dres = None
+        if ctx.has_resid and ctx.needs_input_grad[5]:
+            dres = dy2.reshape(*ctx.xshape[:-1], n)      # (masked by the ReLU when there is one)
+        return (dx.reshape(ctx.xshape) if need_dx else None), dw, db, None, None, dres
 
 
-def linear(x, w, b=None, x_amax=None, relu=False):
-    return LinearFn.apply(x, w, b, x_amax, relu)
+def linear(x, w, b=None, x_amax=None, relu=False, resid=None):
+    return LinearFn.apply(x, w, b, x_amax, relu, resid)
+
+
+class PosHiddenFn(torch.autograd.Function):
+    """h = relu(xyz W0^T + b0) for 3-wide points, one elementwise HIP pass (first layer of the
+    positional-encoding MLP, src/model.py:64-75).  xyz may be a (..., 3) view of wider rows
+    (context[:, :, :3]); it is read in place.  No gradient for xyz."""
+
+    @staticmethod
+    def forward(ctx, xyz, w0, b0):
+        _req_gpu_f32(xyz, "input")
+        _req_gpu_f32(w0, "weight")
+        hdim = w0.shape[0]
+        if xyz.shape[-1] != 3 or w0.shape[1] != 3:
+            raise RuntimeError(f"pos_hidden: expected 3-wide points and a (H, 3) weight, got {tuple(xyz.shape)} and {tuple(w0.shape)}")
+        rows = xyz.numel() // 3
+        # rows must be evenly strided: (B, N, 3) view of contiguous (B, N, C) rows, or contiguous
+        ld = xyz.stride(-2) if xyz.dim() >= 2 else 3
+        ok = xyz.stride(-1) == 1 and ld >= 3
+        for d in range(xyz.dim() - 2):
+            ok = ok and xyz.stride(d) == xyz.stride(d + 1) * xyz.shape[d + 1]
+        if not ok:
+            xyz = xyz.contiguous()
+            ld = 3
+        w0 = w0.contiguous()
+        h = torch.empty((*xyz.shape[:-1], hdim), dtype=torch.float32, device=xyz.device)
+        L.check(L.lib().prh_pos_hidden_forward(_p(xyz), ld, _p(w0), _p(b0), _p(h), rows, hdim,
+                                               xyz.device.index, _stream(xyz.device)), "prh_pos_hidden_forward")
+        ctx.save_for_backward(xyz, h)
+        ctx.ld, ctx.has_bias = ld, b0 is not None
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("pos_hidden: gradient with respect to the points is not implemented")
+        xyz, h = ctx.saved_tensors
+        hdim = h.shape[-1]
+        rows = h.numel() // hdim
+        dev = h.device
+        dh = dh.contiguous()
+        need_dw, need_db = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        dw = torch.empty((hdim, 3), dtype=torch.float32, device=dev) if need_dw else None
+        db = torch.empty(hdim, dtype=torch.float32, device=dev) if need_db else None
+        if need_dw or need_db:
+            ws = _ws(dev, L.lib().prh_pos_hidden_backward_workspace_bytes(rows, hdim))
+            L.check(L.lib().prh_pos_hidden_backward(_p(xyz), ctx.ld, _p(h), _p(dh), _p(dw), _p(db), rows, hdim,
+                                                    _p(ws), ws.numel(), dev.index, _stream(dev)),
+                    "prh_pos_hidden_backward")
+        return None, dw, db
+
+
+def pos_hidden(xyz, w0, b0=None):
+    return PosHiddenFn.apply(xyz, w0, b0)
+
+
+def pos_hidden_supported(hidden):
+    return 4 <= hidden <= 1024 and (hidden & (hidden - 1)) == 0
 
 
 # ------------------------------------------------------------------------------------------
