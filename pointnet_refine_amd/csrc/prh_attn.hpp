@@ -179,6 +179,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
 // writes dK/dV tiles (row-major, 16 B per lane through an LDS transpose) and keeps dQ^T in
 // registers.  LDS per wave: Q, dO, K tiles + one transpose scratch (4 x 4.5 KB).
 // ---------------------------------------------------------------------------------------
+// (242 VGPRs + 96 AGPRs: one wave per SIMD.  Forcing two - __launch_bounds__(256, 2) - spills
+// 64 VGPRs and measured 4 % slower; the kernel runs the fp32 matrix pipe at ~80 % of its peak
+// by the 14-product count below, so occupancy is not what holds it back.)
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

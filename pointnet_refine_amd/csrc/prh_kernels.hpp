@@ -753,13 +753,22 @@ __global__ __launch_bounds__(256) void pos_hidden_bwd_kernel(const float* __rest
 __global__ __launch_bounds__(256) void pos_hidden_final_kernel(const float* __restrict__ part, int nblk,
                                                                int H, float* __restrict__ dw0,
                                                                float* __restrict__ db0) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= 4 * H) return;
+  // 16 elements x 16 slices of the block list per workgroup, then an LDS tree over the slices
+  __shared__ float red[256];
+  const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + el;
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += part[(size_t)b * 4 * H + e];
-  const int col = e >> 2, j = e & 3;
-  if (j < 3) { if (dw0 != nullptr) dw0[col * 3 + j] = s; }
-  else if (db0 != nullptr) db0[col] = s;
+  if (e < 4 * H)
+    for (int b = sl; b < nblk; b += 16) s += part[(size_t)b * 4 * H + e];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (sl == 0 && e < 4 * H) {
+#pragma unroll
+    for (int g = 1; g < 16; ++g) s += red[g * 16 + el];
+    const int col = e >> 2, j = e & 3;
+    if (j < 3) { if (dw0 != nullptr) dw0[col * 3 + j] = s; }
+    else if (db0 != nullptr) db0[col] = s;
+  }
 }
 
 // diagnostic behind prh_test_xcc_map: where the dispatcher put each workgroup

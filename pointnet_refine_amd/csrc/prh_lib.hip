@@ -846,7 +846,7 @@ int prh_pos_hidden_backward(const float* xyz, long ld, const float* h, const flo
   hipLaunchKernelGGL(pos_hidden_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, st, xyz, ld, h, dh, part,
                      rows, hidden);
   LAUNCH_CHECK();
-  hipLaunchKernelGGL(pos_hidden_final_kernel, dim3((unsigned)cdiv(4 * hidden, 256)), dim3(256), 0, st,
+  hipLaunchKernelGGL(pos_hidden_final_kernel, dim3((unsigned)cdiv(4 * hidden, 16)), dim3(256), 0, st,
                      (const float*)part, nb, hidden, dw0, db0);
   LAUNCH_CHECK();
   return PRH_OK;

@@ -8,12 +8,12 @@ timeout -k 10 300 python -m pytest tests/test_gemm_gpu.py tests/test_encoder_gpu
 for rep in 1 2; do
 for lib in default $ALT; do
   if [ $lib = default ]; then unset PRH_LIB_PATH; else export PRH_LIB_PATH=$PWD/$lib; fi
-  timeout -k 10 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --kernels 9 > gpurun_out/bench_ab.json 2> gpurun_out/bench_ab.err || { tail -20 gpurun_out/bench_ab.err; exit 1; }
+  timeout -k 10 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --kernels 40 > gpurun_out/bench_ab.json 2> gpurun_out/bench_ab.err || { tail -20 gpurun_out/bench_ab.err; exit 1; }
   if grep -qi fault gpurun_out/bench_ab.err; then echo FAULT; exit 1; fi
   echo "== $lib: $(python -c "
 import json
 d=json.loads(open('gpurun_out/bench_ab.json').read().strip().splitlines()[-1])
 print(d['ms_per_step'], 'ms/step loss', d['loss'], 'gemm ms', d['roofline']['hip_gemm_ms_per_step'])")"
-  grep "\[bench\] gemm_nt" gpurun_out/bench_ab.err | cut -c9-80
+  grep "attn_\|pos_\|gemm_nt_h2<0,3> K=1024 N=1984" gpurun_out/bench_ab.err | cut -c9-80
 done
 done
