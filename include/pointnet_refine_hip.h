@@ -142,14 +142,25 @@ int prh_linear_forward_res(const float* x, long ldx, const float* w, const float
  * as one elementwise pass: h[r,c] = relu(b0[c] + sum_j xyz[r*ld + j] w0[c*3 + j]), j < 3.
  * xyz rows are read in place with leading dimension ld >= 3 (ld = C for (B,N,C) context rows);
  * hidden: a power of two in [4, 1024].  backward: dw0 [hidden,3] and db0 [hidden] (either may be
- * NULL) from dh [rows,hidden] masked by h > 0; no gradient for xyz (the reference's inputs carry
- * none). */
+ * NULL) from dh [rows,hidden] masked by h > 0; dxyz [rows,3] (contiguous; NULL = skip; needs w0
+ * and hidden <= 256) for the decoder's query positions, which carry gradients. */
 int prh_pos_hidden_forward(const float* xyz, long ld, const float* w0, const float* b0, float* h,
                            long rows, int hidden, int device, void* stream);
 size_t prh_pos_hidden_backward_workspace_bytes(long rows, int hidden);
-int prh_pos_hidden_backward(const float* xyz, long ld, const float* h, const float* dh, float* dw0,
-                            float* db0, long rows, int hidden, void* workspace, size_t workspace_bytes,
-                            int device, void* stream);
+int prh_pos_hidden_backward(const float* xyz, long ld, const float* h, const float* dh, const float* w0,
+                            float* dxyz, float* dw0, float* db0, long rows, int hidden, void* workspace,
+                            size_t workspace_bytes, int device, void* stream);
+
+/* nn.Linear with n <= 4 outputs as one HBM pass (the regression heads' Linear(128, 3),
+ * src/model.py:162-166): y [rows,n] = x [rows,k] w[n,k]^T + b.  k/4 must be a power of two
+ * <= 64 (k = 4 ... 256); x, y, dx contiguous.  backward: dx (NULL = skip), dw [n,k], db [n]
+ * (either may be NULL). */
+int prh_linear_small_forward(const float* x, const float* w, const float* b, float* y, long rows, int k,
+                             int n, int device, void* stream);
+size_t prh_linear_small_backward_workspace_bytes(long rows, int k, int n);
+int prh_linear_small_backward(const float* x, const float* w, const float* dy, float* dx, float* dw,
+                              float* db, long rows, int k, int n, void* workspace, size_t workspace_bytes,
+                              int device, void* stream);
 
 /* nn.Linear backward: dx = dy W (NULL = skip), dw = dy^T x, db = colsum(dy).
  * n and k multiples of 4. */

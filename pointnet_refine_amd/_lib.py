@@ -53,7 +53,8 @@ EXPORTS = [
     "prh_encoder_workspace_bytes", "prh_encoder_forward", "prh_encoder_backward",
     "prh_linear_forward_workspace_bytes", "prh_linear_forward", "prh_linear_forward_ex",
     "prh_linear_forward_res", "prh_pos_hidden_forward", "prh_pos_hidden_backward_workspace_bytes",
-    "prh_pos_hidden_backward",
+    "prh_pos_hidden_backward", "prh_linear_small_forward", "prh_linear_small_backward_workspace_bytes",
+    "prh_linear_small_backward",
     "prh_linear_backward_workspace_bytes", "prh_linear_backward", "prh_linear_backward_ex",
     "prh_mlp_stack_workspace_bytes", "prh_mlp_stack_forward", "prh_mlp_stack_backward",
     "prh_test_gemm_nt", "prh_test_gemm_tn_workspace_bytes", "prh_test_gemm_tn", "prh_test_xcc_map",
@@ -115,7 +116,13 @@ def _bind(lib):
     lib.prh_pos_hidden_backward_workspace_bytes.restype = sz
     lib.prh_pos_hidden_backward_workspace_bytes.argtypes = [lg, i]
     lib.prh_pos_hidden_backward.restype = i
-    lib.prh_pos_hidden_backward.argtypes = [vp, lg, vp, vp, vp, vp, lg, i, vp, sz, i, vp]
+    lib.prh_pos_hidden_backward.argtypes = [vp, lg, vp, vp, vp, vp, vp, vp, lg, i, vp, sz, i, vp]
+    lib.prh_linear_small_forward.restype = i
+    lib.prh_linear_small_forward.argtypes = [vp, vp, vp, vp, lg, i, i, i, vp]
+    lib.prh_linear_small_backward_workspace_bytes.restype = sz
+    lib.prh_linear_small_backward_workspace_bytes.argtypes = [lg, i, i]
+    lib.prh_linear_small_backward.restype = i
+    lib.prh_linear_small_backward.argtypes = [vp, vp, vp, vp, vp, vp, lg, i, i, vp, sz, i, vp]
     lib.prh_linear_backward_ex.restype = i
     lib.prh_linear_backward_ex.argtypes = [vp, lg, vp, vp, vp, vp, vp, i, i, i, vp, vp, vp, sz, i, vp]
     lib.prh_linear_forward_workspace_bytes.restype = sz

@@ -713,12 +713,25 @@ __global__ __launch_bounds__(256) void pos_hidden_fwd_kernel(const float* __rest
 // Its backward: dz = dh * (h > 0); part[block][c*4 + j] = sum_r dz[r,c] * xyz[r,j] (j < 3) and
 // sum_r dz[r,c] (j == 3) over the block's rows.  pos_hidden_final_kernel adds the blocks up
 // (two stages, no atomics: the result does not depend on the launch order).
+// DX: also dxyz[r, j] = sum_c dz[r,c] * w0[c*3 + j] (the decoder's query positions carry
+// gradients, src/model.py:209-231 "no detach"): the row's H/4 threads share a wave (H <= 256)
+// and add their partial sums with shuffles.
+template <bool DX>
 __global__ __launch_bounds__(256) void pos_hidden_bwd_kernel(const float* __restrict__ xyz, long ld,
                                                              const float* __restrict__ h,
                                                              const float* __restrict__ dh,
-                                                             float* __restrict__ part, long P, int H) {
+                                                             float* __restrict__ part, long P, int H,
+                                                             const float* __restrict__ w0,
+                                                             float* __restrict__ dxyz) {
   __shared__ float red[256 * 17];
   const int cg = H >> 2, tc = threadIdx.x % cg, tr = threadIdx.x / cg, rpp = 256 / cg;
+  float w[4][3];
+  if (DX) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) w[c][j] = w0[(4 * tc + c) * 3 + j];
+  }
   float a[4][4];
 #pragma unroll
   for (int c = 0; c < 4; ++c)
@@ -734,6 +747,15 @@ __global__ __launch_bounds__(256) void pos_hidden_bwd_kernel(const float* __rest
     for (int c = 0; c < 4; ++c) {
       a[c][0] = fmaf(dz[c], x0, a[c][0]); a[c][1] = fmaf(dz[c], x1, a[c][1]);
       a[c][2] = fmaf(dz[c], x2, a[c][2]); a[c][3] += dz[c];
+    }
+    if (DX) {
+      float t[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        t[j] = dz[0] * w[0][j] + dz[1] * w[1][j] + dz[2] * w[2][j] + dz[3] * w[3][j];
+        for (int o = cg >> 1; o > 0; o >>= 1) t[j] += __shfl_xor(t[j], o);
+      }
+      if (tc == 0) { dxyz[r * 3] = t[0]; dxyz[r * 3 + 1] = t[1]; dxyz[r * 3 + 2] = t[2]; }
     }
   }
 #pragma unroll
@@ -768,6 +790,115 @@ __global__ __launch_bounds__(256) void pos_hidden_final_kernel(const float* __re
     const int col = e >> 2, j = e & 3;
     if (j < 3) { if (dw0 != nullptr) dw0[col * 3 + j] = s; }
     else if (db0 != nullptr) db0[col] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// nn.Linear with a handful of outputs (the regression heads' Linear(128, 3),
+// src/model.py:162-166): y[r, j] = b[j] + sum_k x[r,k] w[j,k], n <= 4.  HBM work (one read
+// of x), which the library GEMM served with a 16x32 macro-tile at 0.3 ms per 65536 rows.
+// K/4 lanes (a power of two <= 64) share a row: float4 slices of x against register-resident
+// slices of the weight rows, then a shuffle tree.
+// ---------------------------------------------------------------------------------------
+template <int NOUT>
+__global__ __launch_bounds__(256) void linear_small_fwd_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ w,
+                                                               const float* __restrict__ b,
+                                                               float* __restrict__ y, long rows, int K) {
+  const int lpr = K >> 2, tl = threadIdx.x % lpr, tr = threadIdx.x / lpr, rpp = 256 / lpr;
+  float4 wr[NOUT];
+#pragma unroll
+  for (int j = 0; j < NOUT; ++j) wr[j] = ldg4(w + (size_t)j * K + 4 * tl);
+  for (long r0 = (long)blockIdx.x * rpp; r0 < rows; r0 += (long)gridDim.x * rpp) {
+    const long r = r0 + tr;
+    const bool ok = r < rows;                       // whole wave stays in the shuffles
+    const float4 xv = ok ? ldg4(x + r * K + 4 * tl) : zero4();
+    float t[NOUT];
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) {
+      t[j] = xv.x * wr[j].x + xv.y * wr[j].y + xv.z * wr[j].z + xv.w * wr[j].w;
+      for (int o = lpr >> 1; o > 0; o >>= 1) t[j] += __shfl_xor(t[j], o);
+    }
+    if (ok && tl == 0) {
+#pragma unroll
+      for (int j = 0; j < NOUT; ++j) y[r * NOUT + j] = t[j] + (b != nullptr ? b[j] : 0.f);
+    }
+  }
+}
+
+// backward: dx[r,k] = sum_j dy[r,j] w[j,k] (optional);  part[block][j*K + k] = sum_r dy[r,j] x[r,k]
+// and part[block][NOUT*K + j] = sum_r dy[r,j] over the block's rows (linear_small_final_kernel
+// adds the blocks: two stages, no atomics).
+template <int NOUT>
+__global__ __launch_bounds__(256) void linear_small_bwd_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ w,
+                                                               const float* __restrict__ dy,
+                                                               float* __restrict__ dx,
+                                                               float* __restrict__ part, long rows, int K) {
+  __shared__ float red[256 * (4 * NOUT + 1)];
+  const int lpr = K >> 2, tl = threadIdx.x % lpr, tr = threadIdx.x / lpr, rpp = 256 / lpr;
+  constexpr int RS = 4 * NOUT + 1;
+  float4 wr[NOUT], acc[NOUT];
+  float sb[NOUT];
+#pragma unroll
+  for (int j = 0; j < NOUT; ++j) { wr[j] = ldg4(w + (size_t)j * K + 4 * tl); acc[j] = zero4(); sb[j] = 0.f; }
+  for (long r = (long)blockIdx.x * rpp + tr; r < rows; r += (long)gridDim.x * rpp) {
+    const float4 xv = ldg4(x + r * K + 4 * tl);
+    float4 d = zero4();
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) {
+      const float g = dy[r * NOUT + j];
+      d.x = fmaf(g, wr[j].x, d.x); d.y = fmaf(g, wr[j].y, d.y); d.z = fmaf(g, wr[j].z, d.z); d.w = fmaf(g, wr[j].w, d.w);
+      acc[j].x = fmaf(g, xv.x, acc[j].x); acc[j].y = fmaf(g, xv.y, acc[j].y);
+      acc[j].z = fmaf(g, xv.z, acc[j].z); acc[j].w = fmaf(g, xv.w, acc[j].w);
+      sb[j] += g;
+    }
+    if (dx != nullptr) *reinterpret_cast<float4*>(dx + r * K + 4 * tl) = d;
+  }
+#pragma unroll
+  for (int j = 0; j < NOUT; ++j) {
+    red[threadIdx.x * RS + 4 * j] = acc[j].x; red[threadIdx.x * RS + 4 * j + 1] = acc[j].y;
+    red[threadIdx.x * RS + 4 * j + 2] = acc[j].z; red[threadIdx.x * RS + 4 * j + 3] = acc[j].w;
+  }
+  __syncthreads();
+  float* out = part + (size_t)blockIdx.x * (NOUT * K + NOUT);
+  for (int e = threadIdx.x; e < NOUT * K; e += 256) {        // e = j*K + k
+    const int j = e / K, k = e - j * K, tlk = k >> 2, c = k & 3;
+    float s = 0.f;
+    for (int g = 0; g < rpp; ++g) s += red[(g * lpr + tlk) * RS + 4 * j + c];
+    out[e] = s;
+  }
+  __syncthreads();
+  // bias sums: every lane of a row group holds the same sb[] - take lane 0 of each group
+  if (tl == 0) {
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) red[tr * NOUT + j] = sb[j];
+  }
+  __syncthreads();
+  if (threadIdx.x < NOUT) {
+    float s = 0.f;
+    for (int g = 0; g < rpp; ++g) s += red[g * NOUT + threadIdx.x];
+    out[NOUT * K + threadIdx.x] = s;
+  }
+}
+
+// out[e] = sum over blocks of part[block][e], e < n_el (16 elements x 16 block slices per workgroup)
+__global__ __launch_bounds__(256) void partial_rows_final_kernel(const float* __restrict__ part, int nblk,
+                                                                 int n_el, float* __restrict__ out0, int n0,
+                                                                 float* __restrict__ out1) {
+  __shared__ float red[256];
+  const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + el;
+  float s = 0.f;
+  if (e < n_el)
+    for (int b = sl; b < nblk; b += 16) s += part[(size_t)b * n_el + e];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (sl == 0 && e < n_el) {
+#pragma unroll
+    for (int g = 1; g < 16; ++g) s += red[g * 16 + el];
+    if (e < n0) { if (out0 != nullptr) out0[e] = s; }
+    else if (out1 != nullptr) out1[e - n0] = s;
   }
 }
 

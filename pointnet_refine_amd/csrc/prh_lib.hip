@@ -831,10 +831,12 @@ size_t prh_pos_hidden_backward_workspace_bytes(long rows, int hidden) {
   if (!pos_hidden_ok(hidden)) return 0;
   return (size_t)pos_hidden_blocks(rows, hidden) * 4 * hidden * sizeof(float) + 256;
 }
-int prh_pos_hidden_backward(const float* xyz, long ld, const float* h, const float* dh, float* dw0,
-                            float* db0, long rows, int hidden, void* workspace, size_t workspace_bytes,
-                            int device, void* stream) {
+int prh_pos_hidden_backward(const float* xyz, long ld, const float* h, const float* dh, const float* w0,
+                            float* dxyz, float* dw0, float* db0, long rows, int hidden, void* workspace,
+                            size_t workspace_bytes, int device, void* stream) {
   if (!xyz || !h || !dh || rows < 0 || ld < 3) return fail(PRH_ERR_ARG, "pos_hidden_backward: bad argument");
+  if (dxyz != nullptr && (w0 == nullptr || hidden > 256))
+    return fail(PRH_ERR_ARG, "pos_hidden_backward: point gradients need w0 and hidden <= 256 (hidden=%d)", hidden);
   if (!pos_hidden_ok(hidden))
     return fail(PRH_ERR_ARG, "pos_hidden_backward: hidden=%d must be a power of two in [4, 1024]", hidden);
   HIP_TRY(hipSetDevice(device));
@@ -843,11 +845,75 @@ int prh_pos_hidden_backward(const float* xyz, long ld, const float* h, const flo
   float* part = a.f((size_t)nb * 4 * hidden);
   if (!a.ok) return fail(PRH_ERR_WORKSPACE, "pos_hidden_backward: workspace too small (%zu bytes)", workspace_bytes);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(pos_hidden_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, st, xyz, ld, h, dh, part,
-                     rows, hidden);
+  if (dxyz != nullptr)
+    hipLaunchKernelGGL(pos_hidden_bwd_kernel<true>, dim3((unsigned)nb), dim3(256), 0, st, xyz, ld, h, dh, part,
+                       rows, hidden, w0, dxyz);
+  else
+    hipLaunchKernelGGL(pos_hidden_bwd_kernel<false>, dim3((unsigned)nb), dim3(256), 0, st, xyz, ld, h, dh, part,
+                       rows, hidden, w0, dxyz);
   LAUNCH_CHECK();
   hipLaunchKernelGGL(pos_hidden_final_kernel, dim3((unsigned)cdiv(4 * hidden, 16)), dim3(256), 0, st,
                      (const float*)part, nb, hidden, dw0, db0);
+  LAUNCH_CHECK();
+  return PRH_OK;
+}
+
+// ---- nn.Linear with <= 4 outputs (regression heads' last layer, src/model.py:162-166) ----
+static bool linear_small_ok(int k, int n) {
+  const int lpr = k / 4;
+  return n >= 1 && n <= 4 && (k & 3) == 0 && lpr >= 1 && lpr <= 64 && (lpr & (lpr - 1)) == 0;
+}
+static int linear_small_blocks(long rows, int k) {
+  const long rpp = 256 / (k / 4);
+  long nb = (rows + rpp * 8 - 1) / (rpp * 8);
+  return (int)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb));
+}
+int prh_linear_small_forward(const float* x, const float* w, const float* b, float* y, long rows, int k,
+                             int n, int device, void* stream) {
+  if (!x || !w || !y || rows < 0) return fail(PRH_ERR_ARG, "linear_small_forward: bad argument");
+  if (!linear_small_ok(k, n))
+    return fail(PRH_ERR_ARG, "linear_small_forward: needs n <= 4 and k/4 a power of two <= 64 (k=%d n=%d)", k, n);
+  HIP_TRY(hipSetDevice(device));
+  if (rows == 0) return PRH_OK;
+  const long rpp = 256 / (k / 4);
+  long nb = (rows + rpp * 4 - 1) / (rpp * 4);
+  if (nb > 4096) nb = 4096;
+  hipStream_t st = (hipStream_t)stream;
+  switch (n) {
+    case 1: hipLaunchKernelGGL(linear_small_fwd_kernel<1>, dim3((unsigned)nb), dim3(256), 0, st, x, w, b, y, rows, k); break;
+    case 2: hipLaunchKernelGGL(linear_small_fwd_kernel<2>, dim3((unsigned)nb), dim3(256), 0, st, x, w, b, y, rows, k); break;
+    case 3: hipLaunchKernelGGL(linear_small_fwd_kernel<3>, dim3((unsigned)nb), dim3(256), 0, st, x, w, b, y, rows, k); break;
+    default: hipLaunchKernelGGL(linear_small_fwd_kernel<4>, dim3((unsigned)nb), dim3(256), 0, st, x, w, b, y, rows, k); break;
+  }
+  LAUNCH_CHECK();
+  return PRH_OK;
+}
+size_t prh_linear_small_backward_workspace_bytes(long rows, int k, int n) {
+  if (!linear_small_ok(k, n)) return 0;
+  return (size_t)linear_small_blocks(rows, k) * ((size_t)n * k + n) * sizeof(float) + 256;
+}
+int prh_linear_small_backward(const float* x, const float* w, const float* dy, float* dx, float* dw,
+                              float* db, long rows, int k, int n, void* workspace, size_t workspace_bytes,
+                              int device, void* stream) {
+  if (!x || !w || !dy || rows < 0) return fail(PRH_ERR_ARG, "linear_small_backward: bad argument");
+  if (!linear_small_ok(k, n))
+    return fail(PRH_ERR_ARG, "linear_small_backward: needs n <= 4 and k/4 a power of two <= 64 (k=%d n=%d)", k, n);
+  HIP_TRY(hipSetDevice(device));
+  Arena a(workspace, workspace_bytes);
+  const int nb = linear_small_blocks(rows, k);
+  const int n_el = n * k + n;
+  float* part = a.f((size_t)nb * n_el);
+  if (!a.ok) return fail(PRH_ERR_WORKSPACE, "linear_small_backward: workspace too small (%zu bytes)", workspace_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  switch (n) {
+    case 1: hipLaunchKernelGGL(linear_small_bwd_kernel<1>, dim3((unsigned)nb), dim3(256), 0, st, x, w, dy, dx, part, rows, k); break;
+    case 2: hipLaunchKernelGGL(linear_small_bwd_kernel<2>, dim3((unsigned)nb), dim3(256), 0, st, x, w, dy, dx, part, rows, k); break;
+    case 3: hipLaunchKernelGGL(linear_small_bwd_kernel<3>, dim3((unsigned)nb), dim3(256), 0, st, x, w, dy, dx, part, rows, k); break;
+    default: hipLaunchKernelGGL(linear_small_bwd_kernel<4>, dim3((unsigned)nb), dim3(256), 0, st, x, w, dy, dx, part, rows, k); break;
+  }
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(partial_rows_final_kernel, dim3((unsigned)cdiv(n_el, 16)), dim3(256), 0, st,
+                     (const float*)part, nb, n_el, dw, n * k, db);
   LAUNCH_CHECK();
   return PRH_OK;
 }

@@ -124,7 +124,8 @@ class PositionalEncoding(nn.Module):
         """resid: optional tensor added to the encoding (the decoder's k-input memory + pos,
         src/model.py:123-126) - on the GPU it rides on the second Linear's epilogue."""
         l0, l2 = self.mlp[0], self.mlp[2]
-        if (xyz.is_cuda and xyz.dtype == torch.float32 and l0.in_features == 3 and not xyz.requires_grad
+        if (xyz.is_cuda and xyz.dtype == torch.float32 and l0.in_features == 3
+                and (not xyz.requires_grad or l0.out_features <= 256)
                 and ops.pos_hidden_supported(l0.out_features) and l2.out_features % 4 == 0):
             # Linear(3,H)+ReLU: one elementwise HIP pass over the points in place (a 3-deep GEMM
             # is HBM work); Linear(H,H) (+ resid) on the HIP GEMM cores
@@ -280,8 +281,15 @@ class LineRefineNet(nn.Module):
                                                       kv_block=(token, arena, i))
             else:
                 tgt = decoder_layer.forward_projected(tgt, k_split[i], v_split[i], query_pos=pos_tgt)
-            hid = F.relu(_lin(tgt, reg_branch[0].weight, reg_branch[0].bias))       # 256 -> 128 on HIP
-            delta_offset = F.linear(hid, reg_branch[2].weight, reg_branch[2].bias)   # 128 -> 3
+            r0, r2 = reg_branch[0], reg_branch[2]
+            if tgt.is_cuda and r0.in_features % 4 == 0 and r0.out_features % 4 == 0:
+                hid = ops.linear(tgt, r0.weight, r0.bias, None, True)               # 256 -> 128, ReLU in the epilogue
+            else:
+                hid = F.relu(F.linear(tgt, r0.weight, r0.bias))
+            if hid.is_cuda and ops.linear_small_supported(r2.in_features, r2.out_features):
+                delta_offset = ops.linear_small(hid, r2.weight, r2.bias)            # 128 -> 3: one HBM pass
+            else:
+                delta_offset = F.linear(hid, r2.weight, r2.bias)
             current_line_coords = current_line_coords + delta_offset      # no detach (H5)
             all_pred_offsets.append(current_line_coords - noisy_line)
         return torch.stack(all_pred_offsets)

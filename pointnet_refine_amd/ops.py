@@ -148,7 +148,8 @@ def linear(x, w, b=None, x_amax=None, relu=False, resid=None):
 class PosHiddenFn(torch.autograd.Function):
     """h = relu(xyz W0^T + b0) for 3-wide points, one elementwise HIP pass (first layer of the
     positional-encoding MLP, src/model.py:64-75).  xyz may be a (..., 3) view of wider rows
-    (context[:, :, :3]); it is read in place.  No gradient for xyz."""
+    (context[:, :, :3]); it is read in place.  Point gradients (the decoder's query positions)
+    for hidden <= 256."""
 
     @staticmethod
     def forward(ctx, xyz, w0, b0):
@@ -170,28 +171,80 @@ class PosHiddenFn(torch.autograd.Function):
         h = torch.empty((*xyz.shape[:-1], hdim), dtype=torch.float32, device=xyz.device)
         L.check(L.lib().prh_pos_hidden_forward(_p(xyz), ld, _p(w0), _p(b0), _p(h), rows, hdim,
                                                xyz.device.index, _stream(xyz.device)), "prh_pos_hidden_forward")
-        ctx.save_for_backward(xyz, h)
+        ctx.save_for_backward(xyz, h, w0)
         ctx.ld, ctx.has_bias = ld, b0 is not None
         return h
 
     @staticmethod
     def backward(ctx, dh):
-        if ctx.needs_input_grad[0]:
-            raise RuntimeError("pos_hidden: gradient with respect to the points is not implemented")
-        xyz, h = ctx.saved_tensors
+        xyz, h, w0 = ctx.saved_tensors
         hdim = h.shape[-1]
         rows = h.numel() // hdim
         dev = h.device
         dh = dh.contiguous()
+        need_dx = ctx.needs_input_grad[0]
+        if need_dx and hdim > 256:
+            raise RuntimeError("pos_hidden: gradient with respect to the points is implemented for hidden <= 256")
         need_dw, need_db = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        dx = torch.empty((*xyz.shape[:-1], 3), dtype=torch.float32, device=dev) if need_dx else None
         dw = torch.empty((hdim, 3), dtype=torch.float32, device=dev) if need_dw else None
         db = torch.empty(hdim, dtype=torch.float32, device=dev) if need_db else None
-        if need_dw or need_db:
+        if need_dx or need_dw or need_db:
             ws = _ws(dev, L.lib().prh_pos_hidden_backward_workspace_bytes(rows, hdim))
-            L.check(L.lib().prh_pos_hidden_backward(_p(xyz), ctx.ld, _p(h), _p(dh), _p(dw), _p(db), rows, hdim,
-                                                    _p(ws), ws.numel(), dev.index, _stream(dev)),
+            L.check(L.lib().prh_pos_hidden_backward(_p(xyz), ctx.ld, _p(h), _p(dh), _p(w0), _p(dx), _p(dw), _p(db),
+                                                    rows, hdim, _p(ws), ws.numel(), dev.index, _stream(dev)),
                     "prh_pos_hidden_backward")
-        return None, dw, db
+        return dx, dw, db
+
+
+class LinearSmallFn(torch.autograd.Function):
+    """nn.Linear with <= 4 outputs as one HBM pass (regression heads' Linear(128, 3),
+    src/model.py:162-166)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _req_gpu_f32(x, "input")
+        _req_gpu_f32(w, "weight")
+        n, k = w.shape
+        if x.shape[-1] != k:
+            raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({x.shape} and {k}x{n})")
+        x2 = x.reshape(-1, k)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        w = w.contiguous()
+        rows = x2.shape[0]
+        y = torch.empty((rows, n), dtype=torch.float32, device=x.device)
+        L.check(L.lib().prh_linear_small_forward(_p(x2), _p(w), _p(b), _p(y), rows, k, n, x.device.index,
+                                                 _stream(x.device)), "prh_linear_small_forward")
+        ctx.save_for_backward(x2, w)
+        ctx.has_bias, ctx.xshape = b is not None, x.shape
+        return y.reshape(*x.shape[:-1], n)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        n, k = w.shape
+        rows = x2.shape[0]
+        dev = x2.device
+        dy2 = dy.reshape(rows, n).contiguous()
+        need_dx, need_dw, need_db = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        dx = torch.empty_like(x2) if need_dx else None
+        dw = torch.empty_like(w) if need_dw else None
+        db = torch.empty(n, dtype=torch.float32, device=dev) if need_db else None
+        ws = _ws(dev, L.lib().prh_linear_small_backward_workspace_bytes(rows, k, n))
+        L.check(L.lib().prh_linear_small_backward(_p(x2), _p(w), _p(dy2), _p(dx), _p(dw), _p(db), rows, k, n,
+                                                  _p(ws), ws.numel(), dev.index, _stream(dev)),
+                "prh_linear_small_backward")
+        return (dx.reshape(ctx.xshape) if need_dx else None), dw, db
+
+
+def linear_small(x, w, b=None):
+    return LinearSmallFn.apply(x, w, b)
+
+
+def linear_small_supported(k, n):
+    lpr = k // 4
+    return 1 <= n <= 4 and k % 4 == 0 and 1 <= lpr <= 64 and (lpr & (lpr - 1)) == 0
 
 
 def pos_hidden(xyz, w0, b0=None):

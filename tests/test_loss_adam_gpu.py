@@ -23,7 +23,7 @@ def test_l1_deep_supervision_matches_torch():
         crit = torch.nn.L1Loss()
         ref = sum(crit(p2[l], target) for l in range(shape[0])) / shape[0]      # train_dist.py:180-186
         (ref * 3.0).backward()
-        assert abs(float(loss) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+        assert abs(float(loss.detach()) - float(ref.detach())) <= 2e-6 * max(1.0, abs(float(ref.detach())))
         assert maxdiff(pred.grad, p2.grad) <= 1e-9 + 1e-6 * float(p2.grad.abs().max())
         assert float(pred.grad[0, 0, 0, 0]) == 0.0
     # micro-batched use: chunk losses with the full-batch denominator add up

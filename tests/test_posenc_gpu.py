@@ -31,14 +31,57 @@ def test_pos_hidden_fwd_bwd(B, N, C, H):
     assert maxdiff(b0.grad, br.grad) < 2e-6 * rows ** 0.5 * (1 + float(br.grad.abs().max()))
 
 
-def test_pos_hidden_rejects_point_gradients_and_bad_width():
+@pytest.mark.parametrize("B,M,H", [(3, 32, 256), (1, 5, 64), (7, 33, 128), (2, 32, 4)])
+def test_pos_hidden_point_gradients(B, M, H):
+    """The decoder's query positions carry gradients (src/model.py:209-231, no detach)."""
     from pointnet_refine_amd import ops
-    w0 = torch.randn(256, 3, device="cuda", requires_grad=True)
+    g = torch.Generator().manual_seed(B + M + H)
+    xyz = torch.randn(B, M, 3, generator=g).cuda().requires_grad_(True)
+    w0 = (torch.randn(H, 3, generator=g) * 0.5).cuda().requires_grad_(True)
+    b0 = (torch.randn(H, generator=g) * 0.1).cuda().requires_grad_(True)
+    up = torch.randn(B, M, H, generator=g).cuda()
+    ops.pos_hidden(xyz, w0, b0).backward(up)
+    xr, wr, br = (t.detach().double().requires_grad_(True) for t in (xyz, w0, b0))
+    F.relu(F.linear(xr, wr, br)).backward(up.double())
+    assert maxdiff(xyz.grad, xr.grad) < 1e-5 * (1 + float(xr.grad.abs().max()))
+    assert maxdiff(w0.grad, wr.grad) < 1e-5 * (1 + float(wr.grad.abs().max()))
+    assert maxdiff(b0.grad, br.grad) < 1e-5 * (1 + float(br.grad.abs().max()))
+
+
+def test_pos_hidden_rejects_wide_point_gradients_and_bad_width():
+    from pointnet_refine_amd import ops
     xyz = torch.randn(4, 3, device="cuda", requires_grad=True)
-    with pytest.raises(RuntimeError, match="not implemented"):
-        ops.pos_hidden(xyz, w0, None).sum().backward()
+    with pytest.raises(RuntimeError, match="hidden <= 256"):
+        ops.pos_hidden(xyz, torch.randn(512, 3, device="cuda"), None).sum().backward()
     with pytest.raises(RuntimeError, match="power of two"):
         ops.pos_hidden(xyz.detach(), torch.randn(96, 3, device="cuda"), None)
+
+
+@pytest.mark.parametrize("rows,k,n", [(65536, 128, 3), (1, 128, 3), (1000, 256, 4), (333, 16, 1), (77, 64, 2), (5, 4, 3)])
+def test_linear_small_fwd_bwd(rows, k, n):
+    from pointnet_refine_amd import ops
+    g = torch.Generator().manual_seed(rows + k + n)
+    x = torch.randn(rows, k, generator=g).cuda().requires_grad_(True)
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).cuda().requires_grad_(True)
+    b = torch.randn(n, generator=g).cuda().requires_grad_(True)
+    up = torch.randn(rows, n, generator=g).cuda()
+    y = ops.linear_small(x, w, b)
+    y.backward(up)
+    xr, wr, br = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    ref = F.linear(xr, wr, br)
+    ref.backward(up.double())
+    assert y.shape == (rows, n)
+    assert maxdiff(y, ref) < 1e-5
+    assert maxdiff(x.grad, xr.grad) < 1e-5
+    assert maxdiff(w.grad, wr.grad) < 2e-6 * rows ** 0.5 * (1 + float(wr.grad.abs().max()))
+    assert maxdiff(b.grad, br.grad) < 2e-6 * rows ** 0.5 * (1 + float(br.grad.abs().max()))
+
+
+def test_linear_small_rejects_unsupported_shapes():
+    from pointnet_refine_amd import ops
+    with pytest.raises(RuntimeError, match="power of two"):
+        ops.linear_small(torch.randn(8, 96, device="cuda"), torch.randn(3, 96, device="cuda"), None)
+    assert not ops.linear_small_supported(128, 5) and ops.linear_small_supported(128, 3)
 
 
 @pytest.mark.parametrize("mode", [0, 3])
