@@ -131,12 +131,24 @@ int prh_linear_forward_ex(const float* x, long ldx, const float* w, const float*
                           int rows, int k, int n, int relu, const float* x_amax, void* workspace,
                           size_t workspace_bytes, int device, void* stream);
 
-/* Same plus a residual input added in the GEMM epilogue: y = act(x W^T + b + resid), resid
- * [rows,n] (ld ldres) - e.g. k-input = memory + pos_emb(xyz) (src/model.py:123-126) with the
- * addition riding on the second Linear of the positional-encoding MLP. */
-int prh_linear_forward_res(const float* x, long ldx, const float* w, const float* b, const float* resid,
-                           long ldres, float* y, int rows, int k, int n, int relu, const float* x_amax,
-                           void* workspace, size_t workspace_bytes, int device, void* stream);
+/* Same plus an optional residual input added in the GEMM epilogue: y = act(x W^T + b + resid),
+ * resid [rows,n] (ld ldres; NULL = none) - e.g. k-input = memory + pos_emb(xyz)
+ * (src/model.py:123-126) with the addition riding on the second Linear of the
+ * positional-encoding MLP - and an optional device scalar w_amax = max|w|. */
+int prh_linear_forward_full(const float* x, long ldx, const float* w, const float* b, const float* resid,
+                            long ldres, float* y, int rows, int k, int n, int relu, const float* x_amax,
+                            const float* w_amax, void* workspace, size_t workspace_bytes, int device,
+                            void* stream);
+
+/* Operand maxima for the split-fp16 cores, measured once by the caller and handed to every GEMM
+ * that reads the operand (x_amax / w_amax / dy_amax arguments; NULL = the launch measures it):
+ * out[0] = max |x| over [rows, cols] (ld >= cols).  prh_linear_uses_operand_maxima: 1 when a
+ * Linear of this shape runs on those cores in the current GEMM mode (otherwise the maxima are
+ * not read and need not be measured). */
+size_t prh_operand_absmax_workspace_bytes(void);
+int prh_operand_absmax(const float* x, long ld, long rows, int cols, float* out, void* workspace,
+                       size_t workspace_bytes, int device, void* stream);
+int prh_linear_uses_operand_maxima(int rows, int k, int n);
 
 /* First layer of the positional-encoding MLP (src/model.py:64-75, nn.Linear(3, hidden) + ReLU)
  * as one elementwise pass: h[r,c] = relu(b0[c] + sum_j xyz[r*ld + j] w0[c*3 + j]), j < 3.
@@ -174,6 +186,11 @@ int prh_linear_backward_ex(const float* x, long ldx, const float* w, const float
                            float* dw, float* db, int rows, int k, int n, const float* x_amax,
                            const float* dy_amax, void* workspace, size_t workspace_bytes, int device,
                            void* stream);
+/* ... and w_amax = max|w| (the dgrad reads W^T, whose maximum is the same) */
+int prh_linear_backward_full(const float* x, long ldx, const float* w, const float* dy, float* dx,
+                             float* dw, float* db, int rows, int k, int n, const float* x_amax,
+                             const float* dy_amax, const float* w_amax, void* workspace,
+                             size_t workspace_bytes, int device, void* stream);
 
 /* Stack of <= PRH_MAX_LAYERS shared-MLP layers applied to x [P,cin0]:
  * LineRefineNet.point_mlp, src/model.py:150-159,200-201 (relu_last = 0).

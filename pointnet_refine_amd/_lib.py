@@ -52,7 +52,8 @@ class EncoderSaved(C.Structure):
 EXPORTS = [
     "prh_encoder_workspace_bytes", "prh_encoder_forward", "prh_encoder_backward",
     "prh_linear_forward_workspace_bytes", "prh_linear_forward", "prh_linear_forward_ex",
-    "prh_linear_forward_res", "prh_pos_hidden_forward", "prh_pos_hidden_backward_workspace_bytes",
+    "prh_linear_forward_full", "prh_operand_absmax_workspace_bytes", "prh_operand_absmax",
+    "prh_linear_uses_operand_maxima", "prh_linear_backward_full", "prh_pos_hidden_forward", "prh_pos_hidden_backward_workspace_bytes",
     "prh_pos_hidden_backward", "prh_linear_small_forward", "prh_linear_small_backward_workspace_bytes",
     "prh_linear_small_backward",
     "prh_linear_backward_workspace_bytes", "prh_linear_backward", "prh_linear_backward_ex",
@@ -109,8 +110,16 @@ def _bind(lib):
     lib.prh_linear_forward.argtypes = [vp, lg, vp, vp, vp, i, i, i, i, vp, sz, i, vp]
     lib.prh_linear_forward_ex.restype = i
     lib.prh_linear_forward_ex.argtypes = [vp, lg, vp, vp, vp, i, i, i, i, vp, vp, sz, i, vp]
-    lib.prh_linear_forward_res.restype = i
-    lib.prh_linear_forward_res.argtypes = [vp, lg, vp, vp, vp, lg, vp, i, i, i, i, vp, vp, sz, i, vp]
+    lib.prh_linear_forward_full.restype = i
+    lib.prh_linear_forward_full.argtypes = [vp, lg, vp, vp, vp, lg, vp, i, i, i, i, vp, vp, vp, sz, i, vp]
+    lib.prh_operand_absmax_workspace_bytes.restype = sz
+    lib.prh_operand_absmax_workspace_bytes.argtypes = []
+    lib.prh_operand_absmax.restype = i
+    lib.prh_operand_absmax.argtypes = [vp, lg, lg, i, vp, vp, sz, i, vp]
+    lib.prh_linear_uses_operand_maxima.restype = i
+    lib.prh_linear_uses_operand_maxima.argtypes = [i, i, i]
+    lib.prh_linear_backward_full.restype = i
+    lib.prh_linear_backward_full.argtypes = [vp, lg, vp, vp, vp, vp, vp, i, i, i, vp, vp, vp, vp, sz, i, vp]
     lib.prh_pos_hidden_forward.restype = i
     lib.prh_pos_hidden_forward.argtypes = [vp, lg, vp, vp, vp, lg, i, i, vp]
     lib.prh_pos_hidden_backward_workspace_bytes.restype = sz

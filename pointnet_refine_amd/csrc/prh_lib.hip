@@ -212,8 +212,10 @@ int launch_nt(NTParams& p, hipStream_t st, StatInfo* si = nullptr) {   // p.amax
       float* hdr = reinterpret_cast<float*>(p.wprep);
       const char* img = p.wprep + S3_WHDR;
       if (mode == 3) {      // operand scales of the fp16-plane core
-        TRY_RC((measure_absmax<PRO_NONE>(p.W, p.ldw, nullptr, 0, nullptr, nullptr, nullptr, p.N, p.K, hdr, hdr + 64, st)));
-        p.amaxW = hdr;
+        if (p.amaxW == nullptr) {
+          TRY_RC((measure_absmax<PRO_NONE>(p.W, p.ldw, nullptr, 0, nullptr, nullptr, nullptr, p.N, p.K, hdr, hdr + 64, st)));
+          p.amaxW = hdr;
+        }
         if (p.amaxA == nullptr) {
           TRY_RC((measure_absmax<PRO>(p.A, p.lda, p.A2, p.lda2, p.pa, p.pb, p.pc, p.M, p.K, hdr + 1, hdr + 64, st)));
           p.amaxA = hdr + 1;
@@ -229,7 +231,7 @@ int launch_nt(NTParams& p, hipStream_t st, StatInfo* si = nullptr) {   // p.amax
         if (mode == 3 && g_h2_gen2 && vec_ok && lds <= 160 * 1024) {
           const long th2 = (long)NTl * 256 * KT2 * 4;
           hipLaunchKernelGGL(prep_weights_h2_kernel, dim3((unsigned)cdiv(th2, 256)), dim3(256), 0, st, p.W,
-                             p.N, p.K, p.ldw, p.wprep + S3_WHDR, (const float*)hdr);
+                             p.N, p.K, p.ldw, p.wprep + S3_WHDR, p.amaxW);
           LAUNCH_CHECK();
           p.tiles_n = NTl;
           static const int attr_h2 = allow_big_lds(gemm_nt_h2_kernel<PRO, EPI>);
@@ -244,7 +246,7 @@ int launch_nt(NTParams& p, hipStream_t st, StatInfo* si = nullptr) {   // p.amax
         }
       }
       hipLaunchKernelGGL(prep_weights_s3_kernel, dim3((unsigned)cdiv(th, 256)), dim3(256), 0, st,
-                         p.W, p.N, p.K, p.ldw, 0, p.wprep + S3_WHDR, mode == 3 ? (const float*)hdr : nullptr);
+                         p.W, p.N, p.K, p.ldw, 0, p.wprep + S3_WHDR, mode == 3 ? p.amaxW : nullptr);
       LAUNCH_CHECK();
       p.tiles_n = NTl;
       const long tiles = (long)NTl * cdiv(p.M, S3_BM);
@@ -783,16 +785,18 @@ int prh_linear_forward_ex(const float* x, long ldx, const float* w, const float*
   p.amaxA = x_amax;
   return launch_nt<PRO_NONE, EPI_BIAS>(p, (hipStream_t)stream);
 }
-int prh_linear_forward_res(const float* x, long ldx, const float* w, const float* b, const float* resid,
-                           long ldres, float* y, int rows, int k, int n, int relu, const float* x_amax,
-                           void* workspace, size_t workspace_bytes, int device, void* stream) {
-  if (!x || !w || !y || !resid || rows < 0 || k <= 0 || n <= 0 || ldres < n)
-    return fail(PRH_ERR_ARG, "linear_forward_res: bad argument");
+int prh_linear_forward_full(const float* x, long ldx, const float* w, const float* b, const float* resid,
+                            long ldres, float* y, int rows, int k, int n, int relu, const float* x_amax,
+                            const float* w_amax, void* workspace, size_t workspace_bytes, int device,
+                            void* stream) {
+  if (!x || !w || !y || rows < 0 || k <= 0 || n <= 0 || (resid != nullptr && ldres < n))
+    return fail(PRH_ERR_ARG, "linear_forward_full: bad argument");
   HIP_TRY(hipSetDevice(device));
   NTParams p; memset(&p, 0, sizeof(p));
   p.A = x; p.lda = ldx; p.W = w; p.ldw = k; p.C = y; p.ldc = n;
-  p.M = rows; p.N = n; p.K = k; p.bias = b; p.flags = (relu ? F_RELU_OUT : 0) | F_RESID;
+  p.M = rows; p.N = n; p.K = k; p.bias = b; p.flags = (relu ? F_RELU_OUT : 0) | (resid ? F_RESID : 0);
   p.E1 = resid; p.lde1 = ldres;
+  p.amaxW = w_amax;
   if (workspace != nullptr && workspace_bytes >= s3_weight_bytes(n, k) + 256)
     p.wprep = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   p.amaxA = x_amax;
@@ -803,6 +807,25 @@ int prh_linear_forward(const float* x, long ldx, const float* w, const float* b,
                        int device, void* stream) {
   return prh_linear_forward_ex(x, ldx, w, b, y, rows, k, n, relu, nullptr, workspace, workspace_bytes, device,
                                stream);
+}
+
+// ---- operand maxima for the split-fp16 cores, measured once by the caller ---------------
+size_t prh_operand_absmax_workspace_bytes(void) { return (size_t)ABSMAX_MAX_BLOCKS * sizeof(float) + 256; }
+int prh_operand_absmax(const float* x, long ld, long rows, int cols, float* out, void* workspace,
+                       size_t workspace_bytes, int device, void* stream) {
+  if (!x || !out || rows < 0 || cols <= 0 || ld < cols) return fail(PRH_ERR_ARG, "operand_absmax: bad argument");
+  HIP_TRY(hipSetDevice(device));
+  Arena a(workspace, workspace_bytes);
+  float* part = a.f(ABSMAX_MAX_BLOCKS);
+  if (!a.ok) return fail(PRH_ERR_WORKSPACE, "operand_absmax: workspace too small (%zu bytes)", workspace_bytes);
+  TRY_RC((measure_absmax<PRO_NONE>(x, ld, nullptr, 0, nullptr, nullptr, nullptr, rows, cols, out, part,
+                                   (hipStream_t)stream)));
+  return PRH_OK;
+}
+// 1 when a [rows,k] x [n,k]^T Linear GEMM (and its backward GEMMs) run on the split-fp16 cores,
+// i.e. when operand maxima are consumed at all
+int prh_linear_uses_operand_maxima(int rows, int k, int n) {
+  return (gemm_mode() == 3 && (nt_use_s3(rows, n, k) || nt_use_s3(rows, k, n) || tn_use_s3(rows, n, k))) ? 1 : 0;
 }
 
 // ---- positional-encoding MLP, first layer (src/model.py:64-75) -------------------------
@@ -928,6 +951,13 @@ int prh_linear_backward_ex(const float* x, long ldx, const float* w, const float
                            float* dw, float* db, int rows, int k, int n, const float* x_amax,
                            const float* dy_amax_in, void* workspace, size_t workspace_bytes, int device,
                            void* stream) {
+  return prh_linear_backward_full(x, ldx, w, dy, dx, dw, db, rows, k, n, x_amax, dy_amax_in, nullptr, workspace,
+                                  workspace_bytes, device, stream);
+}
+int prh_linear_backward_full(const float* x, long ldx, const float* w, const float* dy, float* dx,
+                             float* dw, float* db, int rows, int k, int n, const float* x_amax,
+                             const float* dy_amax_in, const float* w_amax, void* workspace,
+                             size_t workspace_bytes, int device, void* stream) {
   if (!x || !w || !dy || rows < 0 || k <= 0 || n <= 0) return fail(PRH_ERR_ARG, "linear_backward: bad argument");
   if ((k & 3) || (n & 3)) return fail(PRH_ERR_ARG, "linear_backward: k=%d and n=%d must be multiples of 4", k, n);
   HIP_TRY(hipSetDevice(device));
@@ -944,6 +974,7 @@ int prh_linear_backward_ex(const float* x, long ldx, const float* w, const float
     p.A = dy; p.lda = n; p.W = wT; p.ldw = n; p.C = dx; p.ldc = k; p.M = rows; p.N = k; p.K = n;
     p.wprep = lw.wprep;
     p.amaxA = dy_amax;
+    p.amaxW = w_amax;        // max |W^T| = max |W|
     TRY((launch_nt<PRO_NONE, EPI_BIAS>(p, st)));
     dy_amax = p.amaxA;       // measured once for both GEMMs (lives in the head of lw.wprep)
   }

@@ -57,6 +57,15 @@ def _bn_layer(w, b, g, beta, rm, rv, nbt) -> L.BnLayer:
 # ------------------------------------------------------------------------------------------
 # nn.Linear
 # ------------------------------------------------------------------------------------------
+def operand_absmax(t):
+    """1-element device tensor max|t| of a contiguous 2-D fp32 tensor (prh_operand_absmax)."""
+    out = torch.empty(1, dtype=torch.float32, device=t.device)
+    ws = _ws(t.device, L.lib().prh_operand_absmax_workspace_bytes())
+    L.check(L.lib().prh_operand_absmax(_p(t), t.shape[1], t.shape[0], t.shape[1], _p(out), _p(ws), ws.numel(),
+                                       t.device.index, _stream(t.device)), "prh_operand_absmax")
+    return out
+
+
 class LinearFn(torch.autograd.Function):
     """y = x W^T + b on the fp32 MFMA GEMM core (context_proj, src/model.py:147,194)."""
 
@@ -80,6 +89,7 @@ class LinearFn(torch.autograd.Function):
         rows = x2.shape[0]
         y = torch.empty((rows, n), dtype=torch.float32, device=x.device)
         ws = _ws(x.device, L.lib().prh_linear_forward_workspace_bytes(rows, k, n))
+        r2 = None
         if resid is not None:
             _req_gpu_f32(resid, "residual")
             if tuple(resid.shape) != (*x.shape[:-1], n):
@@ -87,15 +97,19 @@ class LinearFn(torch.autograd.Function):
             r2 = resid.reshape(rows, n)
             if not r2.is_contiguous():
                 r2 = r2.contiguous()
-            L.check(L.lib().prh_linear_forward_res(_p(x2), k, _p(w), _p(b), _p(r2), n, _p(y), rows, k, n,
-                                                   int(bool(relu)), _p(x_amax), _p(ws), ws.numel(),
-                                                   x.device.index, _stream(x.device)),
-                    "prh_linear_forward_res")
-        else:
-            L.check(L.lib().prh_linear_forward_ex(_p(x2), k, _p(w), _p(b), _p(y), rows, k, n, int(bool(relu)), _p(x_amax), _p(ws),
-                                                  ws.numel(), x.device.index, _stream(x.device)),
-                    "prh_linear_forward")
+        # operand maxima of the split-fp16 cores: measured once here and kept for the backward
+        # GEMMs, which read x (wgrad) and W^T (dgrad) again
+        w_amax = None
+        if n % 4 == 0 and L.lib().prh_linear_uses_operand_maxima(rows, k, n):
+            if x_amax is None:
+                x_amax = operand_absmax(x2)
+            w_amax = operand_absmax(w)
+        L.check(L.lib().prh_linear_forward_full(_p(x2), k, _p(w), _p(b), _p(r2), n, _p(y), rows, k, n,
+                                                int(bool(relu)), _p(x_amax), _p(w_amax), _p(ws), ws.numel(),
+                                                x.device.index, _stream(x.device)),
+                "prh_linear_forward")
         ctx.has_resid = resid is not None
+        ctx.w_amax = w_amax
         if relu:
             ctx.save_for_backward(x2, w, y)
         else:
@@ -131,9 +145,9 @@ class LinearFn(torch.autograd.Function):
         db = torch.empty(n, dtype=torch.float32, device=dev) if need_db else None
         nb = L.lib().prh_linear_backward_workspace_bytes(rows, k, n)
         ws = _ws(dev, nb)
-        L.check(L.lib().prh_linear_backward_ex(_p(x2), k, _p(w), _p(dy2), _p(dx), _p(dw), _p(db), rows,
-                                               k, n, _p(ctx.x_amax), _p(dy_amax), _p(ws), ws.numel(), dev.index,
-                                               _stream(dev)),
+        L.check(L.lib().prh_linear_backward_full(_p(x2), k, _p(w), _p(dy2), _p(dx), _p(dw), _p(db), rows,
+                                                 k, n, _p(ctx.x_amax), _p(dy_amax), _p(ctx.w_amax), _p(ws),
+                                                 ws.numel(), dev.index, _stream(dev)),
                 "prh_linear_backward")
         dres = None
         if ctx.has_resid and ctx.needs_input_grad[5]:
