@@ -617,6 +617,7 @@ struct TNParams {
   const float* amaxA;            // fp16-plane core: largest |proA(A)|, |proB(B)| (device; null:
   const float* amaxB;            //   the launch measures them)
   int* pace;                     // transposed-read core: per-split progress counters (zeroed), or null
+  int skew;                      // diagnostic (PRH_TN_SKEW): odd tiles start this many ~2 us naps late
 };
 
 template <int PROA, int PROB>

@@ -291,8 +291,9 @@ __device__ __forceinline__ f16x8 tr_fragment(const char* plane, int col0, int la
 // rows of A and B through its 4 MB L2 - but only while they stay within ~340 rows of each
 // other.  Nothing holds them there, and the launch is bistable: in step, the fusion wgrad at
 // B=4096 fetches 52 GB for 50.5 GB of operands and takes 45 ms; once the tiles have drifted
-// apart the misses keep them apart, and the same launch fetches 160-170 GB and takes 49 ms
-// (both seen, box to box, with rocprofv3 --pmc FETCH_SIZE).  So every TR_PACE k-tiles thread
+// apart the misses keep them apart, and the same launch fetches 160-180 GB and takes 49 ms
+// (both seen, box to box, with rocprofv3 --pmc FETCH_SIZE; profiles/r01u_pmc_wgrad_pacing.txt
+// has both settings on a box that drifts, plus an induced skew).  So every TR_PACE k-tiles thread
 // 0 publishes the block's progress and, when the block is more than one unit ahead of its
 // split's mean, sleeps until the others catch up (the other waves wait at the next barrier).
 // The wait is bounded and abandoned for good after one time-out: blocks that are not
@@ -401,6 +402,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_tr_kernel(const TNParams p) {
       }
     }
   };
+  if (p.skew > 0 && ((tile_m * p.tiles_n + tile_n) & 1))      // diagnostic: knock the tiles out of step
+    for (int i = 0; i < p.skew; ++i) __builtin_amdgcn_s_sleep(64);
   if (KT > 0) {
     load_tile(0, va[0], vb[0]);
     load_tile(1, va[1], vb[1]);

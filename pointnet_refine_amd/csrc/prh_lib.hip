@@ -122,6 +122,7 @@ inline int gemm_mode() {
 // PRH_H2_GEN=1 keeps the split-fp16 NT GEMMs on the first-generation core (32x32x16 MFMA, BK 16)
 bool g_h2_gen2 = [] { const char* e = getenv("PRH_H2_GEN"); return !(e && strcmp(e, "1") == 0); }();
 // PRH_TN_TR=0 keeps the split-fp16 wgrads on the column-staged core
+int g_tn_skew = [] { const char* e = getenv("PRH_TN_SKEW"); return e ? atoi(e) : 0; }();   // diagnostic
 bool g_tn_pace = [] { const char* e = getenv("PRH_TN_PACE"); return !(e && strcmp(e, "0") == 0); }();
 bool g_tn_tr = [] { const char* e = getenv("PRH_TN_TR"); return !(e && strcmp(e, "0") == 0); }();
 inline const char* core_tag() { return gemm_mode() == 2 ? "b1" : (gemm_mode() == 3 ? "h2" : "s3"); }
@@ -374,6 +375,7 @@ int launch_tn(TNParams& p, float* slab, float* colsum_slab, float* C, long ldc, 
         if constexpr (PROA == PRO_NONE && (PROB == PRO_NONE || PROB == PRO_BNRELU))
           tr = mode == 3 && g_tn_tr && ((p.Mo | p.Ni | (int)p.lda | (int)p.ldb) & 3) == 0;
         p.pace = nullptr;
+        p.skew = g_tn_skew > 0 ? (g_tn_skew > 1000 ? 1000 : g_tn_skew) : 0;
         // (only where many tiles share long splits: with 6 tiles per split the waits cost the
         // attention K/V wgrad 7 % and there is little to share)
         if (tr && g_tn_pace && pl.tiles_m * pl.tiles_n >= 8 && pl.splits <= ABSMAX_MAX_BLOCKS &&

@@ -1,16 +1,19 @@
 #!/bin/bash
 # XCD map, then L2 fetch traffic of one fusion-wgrad-shaped launch (scripts/tn_probe.py)
-# without and with pacing (PRH_TN_PACE)
+# without and with pacing (PRH_TN_PACE), undisturbed and with the odd tiles started
+# ~100 us late (PRH_TN_SKEW, diagnostic) - what pacing is there to repair
 set -e
 OUT=${1:-pmc_tn}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/$OUT
 python scripts/tn_probe.py 4194304 1024 1984 2 2>/dev/null | grep -v finite
+for skew in 0 50; do
 for pace in 0 1; do
-  c=FETCH_SIZE; tag=pace${pace}_$c
-  PRH_TN_PACE=$pace rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/$OUT/$tag -- python scripts/tn_probe.py > gpurun_out/$OUT/$tag.log 2>&1 || { echo "pass $tag failed"; tail -5 gpurun_out/$OUT/$tag.log; exit 1; }
+  c=FETCH_SIZE; tag=skew${skew}_pace${pace}_$c
+  PRH_TN_SKEW=$skew PRH_TN_PACE=$pace rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/$OUT/$tag -- python scripts/tn_probe.py > gpurun_out/$OUT/$tag.log 2>&1 || { echo "pass $tag failed"; tail -5 gpurun_out/$OUT/$tag.log; exit 1; }
   if grep -q "fault" gpurun_out/$OUT/$tag.log; then echo FAULT; exit 1; fi
   echo "pass $tag done: $(grep 'ms per call' gpurun_out/$OUT/$tag.log)"
+done
 done
 python - "$OUT" <<'PY'
 import collections, csv, glob, os, sys
