@@ -502,7 +502,10 @@ __device__ __forceinline__ void nt_epilogue_vec(ACC& acc, const NTParams& p, int
   }
 }
 
-template <int PRO, int EPI>
+// NARROW: N <= 64 (one column tile).  The 2x2 wave grid then covers 128 x 64 with 64 x 32 wave
+// tiles instead of spending half of every MFMA on columns that do not exist (the intensity
+// gate's dgrad, K=1024 N=64, ran at 80 % of the fp32 matrix peak with half of it wasted).
+template <int PRO, int EPI, bool NARROW = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NTParams p) {
   __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * BK];
   float* As = smem;
@@ -510,7 +513,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NTParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  constexpr int NTW = NARROW ? 1 : 2;          // 32-column blocks per wave
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * (NARROW ? 32 : 64);
   const int vb = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_n = vb % p.tiles_n, tile_m = vb / p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -518,11 +522,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NTParams p) {
   const int sr = tid >> 3;         // staging row 0..31 (+32*j)
   const int sk = (tid & 7) * 4;    // staging k offset inside the k-tile
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NTW];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NTW; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -544,7 +548,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NTParams p) {
         if (PRO == PRO_BNBWD) ra2[j] = ok ? ldg4(p.A2 + (size_t)row * p.lda2 + k) : zero4();
       }
       const int n = n0 + sr + 32 * j;
-      rw[j] = (kok && n < p.N) ? ldg4(p.W + (size_t)n * p.ldw + k) : zero4();
+      if (!NARROW || j < 2) rw[j] = (kok && n < p.N) ? ldg4(p.W + (size_t)n * p.ldw + k) : zero4();
     }
   };
   auto store_tile = [&](int kt) {
@@ -562,7 +566,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NTParams p) {
       const bool ok = kok && (m0 + r) < p.M;
       float4 v = ok ? pro_apply<PRO>(ra[j], ra2[j], ka, kb, kc) : zero4();
       *reinterpret_cast<float4*>(As + lds_off(r, sk >> 2)) = v;
-      *reinterpret_cast<float4*>(Ws + lds_off(r, sk >> 2)) = rw[j];
+      if (!NARROW || j < 2) *reinterpret_cast<float4*>(Ws + lds_off(r, sk >> 2)) = rw[j];
     }
   };
 
@@ -574,16 +578,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NTParams p) {
     if (kt + 1 < nk) load_tile(kt + 1);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      float4 a4[2], b4[2];
+      float4 a4[2], b4[NTW];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < 2; ++t)
         a4[t] = *reinterpret_cast<const float4*>(As + lds_off(wm + t * 32 + l31, g * 2 + half));
+#pragma unroll
+      for (int t = 0; t < NTW; ++t)
         b4[t] = *reinterpret_cast<const float4*>(Ws + lds_off(wn + t * 32 + l31, g * 2 + half));
-      }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NTW; ++j) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].x, b4[j].x, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].y, b4[j].y, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].z, b4[j].z, acc[i][j], 0, 0, 0);
@@ -597,7 +602,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NTParams p) {
     }
   }
 
-  nt_epilogue<EPI, 2, 2>(acc, p, m0 + wm, n0 + wn, tile_m * 2 + (wave >> 1), lane);
+  nt_epilogue<EPI, 2, NTW>(acc, p, m0 + wm, n0 + wn, tile_m * 2 + (wave >> 1), lane);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -620,7 +625,8 @@ struct TNParams {
   int skew;                      // diagnostic (PRH_TN_SKEW): odd tiles start this many ~2 us naps late
 };
 
-template <int PROA, int PROB>
+// NARROW: Ni <= 64 (one column tile): 64 x 32 wave tiles, as in gemm_nt_kernel
+template <int PROA, int PROB, bool NARROW = false>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TNParams p) {
   __shared__ __attribute__((aligned(16))) float smem[2 * BK * 128];
   float* As = smem;              // [BK][128]  (k = point rows, m contiguous)
@@ -628,7 +634,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TNParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  constexpr int NTW = NARROW ? 1 : 2;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * (NARROW ? 32 : 64);
   // XCD-aware id: the tiles of one row split run on one XCD, so the split's rows of A and B
   // are fetched into that L2 once and shared by its tiles_m x tiles_n blocks
   int b = xcd_remap(blockIdx.x, gridDim.x);
@@ -643,11 +650,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TNParams p) {
   const int sc = (tid & 31) * 4;   // staging column (float4)
   const int sr = tid >> 5;         // staging row 0..7 (+8*j)
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NTW];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NTW; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -705,16 +712,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TNParams p) {
     if (kt + 1 < nk) load_tile(kt + 1);
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
-      float a[2], bb[2];
+      float a[2], bb[NTW];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        a[t] = As[(kk * 2 + half) * 128 + wm + t * 32 + l31];
-        bb[t] = Bs[(kk * 2 + half) * 128 + wn + t * 32 + l31];
-      }
+      for (int t = 0; t < 2; ++t) a[t] = As[(kk * 2 + half) * 128 + wm + t * 32 + l31];
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) bb[t] = Bs[(kk * 2 + half) * 128 + wn + t * 32 + l31];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NTW; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
@@ -728,7 +734,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TNParams p) {
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
+    for (int nt = 0; nt < NTW; ++nt) {
       const int col = n0 + wn + nt * 32 + l31;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {

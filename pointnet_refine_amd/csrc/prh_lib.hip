@@ -277,7 +277,10 @@ int launch_nt(NTParams& p, hipStream_t st, StatInfo* si = nullptr) {   // p.amax
   const long tiles = (long)p.tiles_n * cdiv(p.M, BM);
   snprintf(nm, sizeof(nm), "gemm_nt<%d,%d> K=%d N=%d", PRO, EPI, p.K, p.N);
   ProfScope ps(nm, 2.0 * p.M * (double)p.N * p.K, by, st);
-  hipLaunchKernelGGL((gemm_nt_kernel<PRO, EPI>), dim3((unsigned)tiles), dim3(256), 0, st, p);
+  if (p.N <= 64)      // one column tile: 64 x 32 wave tiles
+    hipLaunchKernelGGL((gemm_nt_kernel<PRO, EPI, true>), dim3((unsigned)tiles), dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((gemm_nt_kernel<PRO, EPI>), dim3((unsigned)tiles), dim3(256), 0, st, p);
   LAUNCH_CHECK();
   if (si) { si->count = 2 * cdiv(p.M, BM); si->rows = 64; }
   return PRH_OK;
@@ -410,7 +413,10 @@ int launch_tn(TNParams& p, float* slab, float* colsum_slab, float* C, long ldc, 
     if (!done) {
       snprintf(nm, sizeof(nm), "gemm_tn<%d,%d> Mo=%d Ni=%d", PROA, PROB, p.Mo, p.Ni);
       ProfScope ps(nm, 2.0 * p.P * (double)p.Mo * p.Ni, by, st);
-      hipLaunchKernelGGL((gemm_tn_kernel<PROA, PROB>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+      if (p.Ni <= 64)
+        hipLaunchKernelGGL((gemm_tn_kernel<PROA, PROB, true>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+      else
+        hipLaunchKernelGGL((gemm_tn_kernel<PROA, PROB>), dim3((unsigned)blocks), dim3(256), 0, st, p);
     }
   }
   LAUNCH_CHECK();
