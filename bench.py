@@ -145,7 +145,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    from pointnet_refine_amd import _lib
+    from pointnet_refine_amd import _lib, ops
     from pointnet_refine_amd.model import LineRefineNet
     from pointnet_refine_amd.synth import synthetic_batch
     from pointnet_refine_amd.train_step import TrainStep
@@ -194,8 +194,10 @@ def main():
         # step after the timed region supplies the per-kernel figures of the roofline object
         lib.prh_profile_reset()
         step.use_graph = False
+        step.close()                     # the graph's pool and an eager step do not fit together at B=4096
+        ops.release_workspaces()
+        torch.cuda.empty_cache()
         step(ctx, noisy, target)
-        step.use_graph = True
         sync()
     # per-kernel live durations (HIP events on the launch stream)
     agg = {}

@@ -193,8 +193,10 @@ class TrainStep:
         return total
 
     def close(self):
-        """Unregister the device seed counter of a graph-captured step (the library keeps the
-        pointer it was given; call this - or drop the TrainStep - before freeing GPU memory)."""
+        """Drop the captured graph (its private memory pool goes back to the allocator) and
+        unregister the device seed counter (the library keeps the pointer it was given; call
+        this - or drop the TrainStep - before freeing GPU memory).  The step falls back to eager
+        launches; a later call with graph=True captures again."""
         if getattr(self, "_seed", None) is not None:
             try:
                 from . import _lib as L
@@ -202,6 +204,7 @@ class TrainStep:
             except Exception:
                 pass
             self._seed = None
+        self._graph, self._static, self._static_loss = None, None, None
 
     def __del__(self):
         self.close()
@@ -224,6 +227,13 @@ class TrainStep:
                 self.grads.flat.zero_()
                 self.forward_backward(*self._static)
         torch.cuda.current_stream(dev).wait_stream(side)
+        # the capture allocates from a private pool, which cannot reuse what the warm-up left in
+        # the default pool - its cached blocks and the per-stream scratch buffers of ops._ws
+        # (tens of GB at B=4096): hand them back first, or the two pools together exceed 288 GB
+        torch.cuda.synchronize(dev)
+        from . import ops as _ops
+        _ops.release_workspaces()
+        torch.cuda.empty_cache()
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
             self._seed.add_(1)
