@@ -1,67 +1,62 @@
 #!/usr/bin/env python
 """Benchmark of the LineRefineNet hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N=1: plain process)
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W
+
+With N > 1 and no RANK in the environment this process only LAUNCHES: it starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...
+bench.py <same flags>` as a child (run_dist_train.sh:16 of the reference does the same with
+torchrun) and never touches the GPU itself; under an external torchrun (RANK set) it is a
+rank.  One process per GPU, RCCL ("nccl" backend) over xGMI.
 
 One STEP = one training pass over one synthetic batch per GPU, exactly what
-train_dist.py:173-189 does per iteration: zero_grad, forward, deep-supervision L1 loss,
-backward (DDP gradient all-reduce over RCCL when N>1), Adam step.  fp32 throughout (the
-reference's dtype; the 1e-4 parity gate applies to this path).  Inputs are generated on the
-device before the timed region.  Weak scaling: every rank processes --batch segments.
+train_dist.py:173-189 does per iteration: buffer broadcast, zero_grad, forward,
+deep-supervision L1 loss, backward, gradient all-reduce (mean), Adam step.  Inputs are
+generated on the device before the timed region.  Weak scaling: every rank processes --batch
+segments.
 
-Prints ONE JSON line on rank 0 (contract in the task brief) with two extra objects:
+Rank 0 prints ONE JSON line (contract in the task brief) with these extra objects:
   roofline      the dominant kernel of the timed region, timed live with HIP events on its
-                launch stream (library profiler), against the fp32 MFMA peak
-  cpu_baseline  the oracle (CPU restatement of the reference, kind "port") timed on the
-                host cores on a bounded sample of the same workload (rank 0, N=1 only)
+                launch stream (library profiler), against the peak of the MFMA products it
+                issues; roofline.step = whole-step algorithmic FLOPs over the step time
+  parity        one more step at the benchmark size, on the same inputs, weights and dropout
+                seeds, with the exact-fp32 MFMA cores (PRH_GEMM=fp32) next to one with the
+                benchmarked cores: max |out| difference and worst per-tensor gradient rel-L2
+  cpu_baseline  the oracle (CPU restatement of the reference, kind "port") timed on the host
+                cores on a bounded sample of the same workload (rank 0, N=1 only): full
+                fwd+bwd (= value), encoder-only fwd+bwd, eval forward
 """
 import argparse
-import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
-BF16_MFMA_PEAK_TFLOPS = 2500.0     # dense v_mfma_f32_32x32x16_bf16
-SPLIT_PRODUCTS = 6                 # bf16 MFMA products per fp32-accurate MAC on the split cores
-SPLIT16_PRODUCTS = 3               # fp16 MFMA products per fp32-accurate MAC on the split-fp16 cores
-DEFAULT_GEMM = "split16"
-PMC_TRAFFIC_FILE = "r01q_pmc_traffic_B4096.json"
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # dense v_mfma_f32_{32x32x16,16x16x32}_{bf16,f16}
 HBM_PEAK_GBS = 8000.0
-
-
-def pmc_traffic(dname, batch, points, mode):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes
-    (profiles/r01f_pmc_traffic_B4096.json: FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc
-    runs of this same command, scripts/pmc_traffic.sh).  Counters cannot be read from inside
-    the benchmark, so this is a lookup valid for the configuration it was taken on (default
-    GEMM mode, B=4096, N=1024); null otherwise."""
-    path = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)
-    if not (os.path.exists(path) and batch == 4096 and points == 1024 and mode == 3):
-        return None
-    import re
-    m = re.match(r"gemm_(nt|tn)_h2(tr)?<(\d),(\d)>", dname)
-    if not m:
-        return None
-    if m.group(1) == "tn" and m.group(2):      # wgrad core with transposed fragment reads
-        tmpl = f"prh::gemm_tn_tr_kernel<{m.group(4)}>"
-    elif m.group(1) == "tn":                   # column-staged wgrad core, two fp16 planes
-        tmpl = f"prh::gemm_tn_s3_kernel<{m.group(3)}, {m.group(4)}, 2>"
-    else:
-        tmpl = f"prh::gemm_nt_h2_kernel<{m.group(3)}, {m.group(4)}>"
-    cands = [r for r in json.load(open(path)) if r["kernel"] == tmpl]
-    if not cands:
-        return None
-    r = max(cands, key=lambda r: r["fetch_bytes_largest_launch"])      # the fusion-layer launch
-    return r["fetch_bytes_largest_launch"] + (r["write_bytes_largest_launch"] or 0.0)
+GEMM_MODES = {"fp32": 0, "split": 1, "bf16op": 2, "split16": 3, "bf16": 4}
+DEFAULT_GEMM = "split16"
+PMC_TRAFFIC_FILES = {3: "r01q_pmc_traffic_B4096.json"}      # gemm mode -> committed PMC pass
+# MFMA products issued per algorithmic MAC and what the peak is quoted on, per gemm mode
+MODE_INFO = {
+    0: (1, FP32_MFMA_PEAK_TFLOPS, "157.3 TF fp32 MFMA (v_mfma_f32_32x32x2_f32)",
+        "f32"),
+    1: (6, BF16_MFMA_PEAK_TFLOPS, "2500 TF dense bf16 MFMA / 6 products per fp32-accurate MAC (3-plane bf16 split)",
+        "f32 (large GEMMs: 3xbf16-split MFMA, fp32 accumulate)"),
+    2: (1, BF16_MFMA_PEAK_TFLOPS, "2500 TF dense bf16 MFMA",
+        "bf16 MFMA operands, fp32 accumulate and storage (reduced precision)"),
+    3: (3, BF16_MFMA_PEAK_TFLOPS, "2500 TF dense fp16 MFMA / 3 products per fp32-accurate MAC (2 scaled fp16 planes)",
+        "f32 (large GEMMs: 2xfp16-split MFMA, 3 products, fp32 accumulate)"),
+    4: (1, BF16_MFMA_PEAK_TFLOPS, "2500 TF dense bf16 MFMA (v_mfma_f32_16x16x32_bf16)",
+        "bf16 (encoder activations and their gradients stored in bf16, bf16 MFMA operands everywhere; "
+        "fp32 accumulate, statistics, attention core, master weights and optimiser)"),
+}
 
 
 def parse():
@@ -72,25 +67,49 @@ def parse():
     ap.add_argument("--batch", type=int, default=4096, help="segments per GPU per step")
     ap.add_argument("--points", type=int, default=1024, help="context points per segment")
     ap.add_argument("--decoder-chunk", type=int, default=2048,
-                    help="segments per decoder micro-batch (bounds the stock-PyTorch decoder's "
-                         "activation memory; results are identical to the unchunked step)")
-    ap.add_argument("--gemm", choices=["split16", "split", "fp32", "bf16"], default=DEFAULT_GEMM,
+                    help="segments per decoder micro-batch (bounds the decoder's activation memory; "
+                         "results are identical to the unchunked step)")
+    ap.add_argument("--gemm", choices=sorted(GEMM_MODES), default=DEFAULT_GEMM,
                     help="GEMM cores for the large GEMMs. split16 = two scaled fp16 planes, 3 MFMA "
-                         "products, fp32-level error; split = three bf16 planes, 6 products, fp32-level "
-                         "error, no range assumption; fp32 = exact fp32 MFMA everywhere; bf16 = reduced "
-                         "precision (config 3)")
+                         "products, fp32-level error (default); split = three bf16 planes, 6 products; "
+                         "fp32 = exact fp32 MFMA everywhere; bf16 = BASELINE config 3: bf16 operands AND "
+                         "bf16 activation storage; bf16op = bf16 operands on fp32 storage (round-1 toggle)")
     ap.add_argument("--graph", action="store_true",
                     help="capture forward+loss+backward in a HIP graph (small, launch-bound batches)")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of the fused flat-buffer Adam")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the exact-fp32 parity step after the timed region")
     ap.add_argument("--kernels", type=int, default=0, help="print the K longest GEMM launches (live HIP-event times) to stderr")
-    ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--cpu-batch", type=int, default=64)
+    ap.add_argument("--stub", action="store_true",
+                    help="launcher self-test: a small CPU stand-in model over the gloo backend instead of "
+                         "the HIP model over RCCL (tests/test_bench_launcher_cpu.py); not a measurement")
     return ap.parse_args()
 
 
-def l1_deep_supervision(out, target):
-    """train_dist.py:180-186: mean over the 6 layers of nn.L1Loss(pred_l, target)."""
-    return (out - target.unsqueeze(0)).abs().mean()
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args):
+    """N > 1 without a launcher: become one.  Nothing here touches the GPU (not even
+    torch.cuda.is_available()); the ranks are fresh child processes."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    log("launching", " ".join(cmd))
+    return subprocess.call(cmd, env=env)
 
 
 def host_cores():
@@ -106,80 +125,242 @@ def host_cores():
     return max(1, min(n, 16))
 
 
-def log(*a):
-    print("[bench]", *a, file=sys.stderr, flush=True)
+def step_flops(batch, points, line_points=32):
+    """Algorithmic FLOPs of one training step per GPU (SURVEY.md 8(d) / BASELINE.md section 3):
+    forward 2*MAC = 8,013,952*N + 12,482,432*M per segment, forward+backward = 3x."""
+    return 3.0 * batch * (8_013_952.0 * points + 12_482_432.0 * line_points)
 
 
 def cpu_baseline(points, batch):
-    """Oracle (port of the reference) fwd+bwd on the host cores: bounded sample."""
+    """Oracle (port of the reference) on the host cores, bounded sample: the three figures of
+    BASELINE.md section 4 - (a) full forward+backward, (b) encoder-only forward+backward,
+    (c) eval forward - 1 warm-up + best of 2 each."""
+    import torch
     from oracle import linerefine_oracle as O
     from oracle import procedural as P
     torch.set_num_threads(host_cores())
+    nt = torch.get_num_threads()
     sd = P.linerefine_state_dict(0)
     ctx, noisy, target = P.synth_batch(batch, points, 4, 32, seed=1234)
-    best = float("inf")
-    for it in range(3):
+
+    def full():
         p = O.as_params(sd, requires_grad=True)
-        t0 = time.perf_counter()
         out = O.linerefine_forward(p, ctx, noisy, training=True, new_stats={})
         O.deep_supervision_l1(out, target).backward()
-        dt = time.perf_counter() - t0
-        log(f"cpu_baseline iter {it}: {dt:.2f} s on {torch.get_num_threads()} threads")
-        if it > 0:
-            best = min(best, dt)
-    return {"value": round(batch / best, 3), "unit": "segments/s", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": f"oracle/linerefine_oracle.py fwd+bwd (no optimizer), B={batch}, N={points}, fp32, "
-                      f"torch-CPU {torch.get_num_threads()} threads, 1 warm-up + best of 2"}
+
+    def encoder():
+        p = O.as_params(sd, requires_grad=True)
+        g, f = O.encoder_forward(p, ctx, "context_encoder.", True, {})
+        (f.square().mean() + g.square().mean()).backward()
+
+    def evalf():
+        p = O.as_params(sd, requires_grad=False)
+        with torch.no_grad():
+            O.linerefine_forward(p, ctx, noisy, training=False)
+
+    res = {}
+    for name, fn in (("full_fwd_bwd", full), ("encoder_fwd_bwd", encoder), ("eval_forward", evalf)):
+        best = float("inf")
+        for it in range(3):
+            t0 = time.perf_counter()
+            fn()
+            dt = time.perf_counter() - t0
+            log(f"cpu_baseline {name} iter {it}: {dt:.2f} s on {nt} threads")
+            if it > 0:
+                best = min(best, dt)
+        res[name] = round(batch / best, 3)
+    return {"value": res["full_fwd_bwd"], "unit": "segments/s", "cores": nt, "kind": "port",
+            "encoder_fwd_bwd": res["encoder_fwd_bwd"], "eval_forward": res["eval_forward"],
+            "sample": f"oracle/linerefine_oracle.py, B={batch}, N={points}, fp32, torch-CPU {nt} threads, "
+                      f"1 warm-up + best of 2 each: value = full forward+backward (no optimizer); "
+                      f"encoder_fwd_bwd = MultiScalePointNetEncoder alone; eval_forward = no_grad forward"}
 
 
-def main():
-    args = parse()
+def pmc_traffic(dname, batch, points, mode):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE x2
+    + WRITE_SIZE, separate rocprofv3 --pmc runs of this same command, scripts/pmc_traffic.sh).
+    Counters cannot be read from inside the benchmark, so this is a lookup valid for the
+    configuration it was taken on (that GEMM mode, B=4096, N=1024); null otherwise."""
+    import re
+    fn = PMC_TRAFFIC_FILES.get(mode)
+    if fn is None or not (batch == 4096 and points == 1024):
+        return None, None
+    path = os.path.join(ROOT, "profiles", fn)
+    if not os.path.exists(path):
+        return None, None
+    m = re.match(r"gemm_(nt|tn)_(h2|b16)(tr)?<(\d),(\d)>", dname)
+    if not m:
+        return None, fn
+    if m.group(2) == "b16":
+        tmpl = ("prh::gemm_tn_b16_kernel" if m.group(1) == "tn" else "prh::gemm_nt_b16_kernel")
+        cands = [r for r in json.load(open(path)) if r["kernel"].startswith(tmpl)]
+    else:
+        if m.group(1) == "tn" and m.group(3):      # wgrad core with transposed fragment reads
+            tmpl = f"prh::gemm_tn_tr_kernel<{m.group(5)}>"
+        elif m.group(1) == "tn":                   # column-staged wgrad core, two fp16 planes
+            tmpl = f"prh::gemm_tn_s3_kernel<{m.group(4)}, {m.group(5)}, 2>"
+        else:
+            tmpl = f"prh::gemm_nt_h2_kernel<{m.group(4)}, {m.group(5)}>"
+        cands = [r for r in json.load(open(path)) if r["kernel"] == tmpl]
+    if not cands:
+        return None, fn
+    r = max(cands, key=lambda r: r["fetch_bytes_largest_launch"])      # the fusion-layer launch
+    return r["fetch_bytes_largest_launch"] + (r["write_bytes_largest_launch"] or 0.0), fn
+
+
+class StubNet:
+    """CPU stand-in with the model's call contract, for the launcher self-test (--stub)."""
+
+    @staticmethod
+    def build():
+        import torch
+
+        class Tiny(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.l1 = torch.nn.Linear(4, 16)
+                self.bn = torch.nn.BatchNorm1d(16)
+                self.l2 = torch.nn.Linear(16, 3)
+
+            def forward(self, context, noisy_line):
+                h = torch.relu(self.bn(self.l1(context.reshape(-1, 4))))
+                g = h.reshape(context.shape[0], -1, 16).max(dim=1)[0]
+                off = self.l2(g).unsqueeze(1) + 0 * noisy_line
+                return torch.stack([off + noisy_line * 0.1 * l for l in range(6)])
+
+        return Tiny()
+
+
+def parity_check(step, model, batch, lib, mode, dev):
+    """One step at the benchmark size with the benchmarked GEMM cores and one with the exact-fp32
+    MFMA cores: same inputs, same weights and BatchNorm buffers, same dropout seeds (the hash
+    masks are functions of seeds drawn from torch's CPU generator).  No optimiser step."""
+    import torch
+    from pointnet_refine_amd import ops
+    snap = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    res = {}
+    step.keep_out = True
+    try:
+        for tag, m in (("bench", mode), ("exact", 0)):
+            lib.prh_set_gemm_mode(m)
+            with torch.no_grad():
+                for k, v in model.state_dict().items():
+                    v.copy_(snap[k])
+            torch.manual_seed(20240217)
+            step.grads.zero()
+            loss = step.forward_backward(*batch)
+            torch.cuda.synchronize(dev)
+            res[tag] = (step.last_out.clone(), step.grads.flat.clone(), float(loss))
+            step.last_out = None
+            ops.release_workspaces()
+            torch.cuda.empty_cache()
+    finally:
+        step.keep_out = False
+        lib.prh_set_gemm_mode(mode)
+        with torch.no_grad():
+            for k, v in model.state_dict().items():
+                v.copy_(snap[k])
+    (oa, ga, la), (ob, gb, lb) = res["bench"], res["exact"]
+    out_err = float((oa - ob).abs().max())
+    worst, worst_name, off = 0.0, "", 0
+    gmax = 0.0
+    per = []
+    for n, p in zip(names, step.grads.params):
+        k = p.numel()
+        a, b = ga[off:off + k].double(), gb[off:off + k].double()
+        off += k
+        per.append((n, float(b.norm()), float((a - b).norm())))
+        gmax = max(gmax, per[-1][1])
+    for n, bn, dn in per:
+        if bn > 1e-7 * gmax and bn > 0:          # tensors that receive a gradient at all
+            r = dn / bn
+            if r > worst:
+                worst, worst_name = r, n
+    total = float((ga.double() - gb.double()).norm() / (gb.double().norm() + 1e-30))
+    return {"out_max_abs_vs_exact_fp32": out_err, "worst_grad_rel_l2": worst, "worst_grad": worst_name,
+            "all_grads_rel_l2": total, "loss": la, "loss_exact_fp32": lb}
+
+
+def run(args):
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ      # torchrun / torch.distributed.run
     if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")     # RCCL on ROCm
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        dist.init_process_group(backend="gloo" if args.stub else "nccl")     # "nccl" = RCCL on ROCm
+    if args.stub:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
 
-    from pointnet_refine_amd import _lib, ops
-    from pointnet_refine_amd.model import LineRefineNet
-    from pointnet_refine_amd.synth import synthetic_batch
     from pointnet_refine_amd.train_step import TrainStep
-    lib = _lib.lib()
-    lib.prh_set_gemm_mode({"fp32": 0, "split": 1, "bf16": 2, "split16": 3}[args.gemm])
-
+    lib = None
+    mode = GEMM_MODES[args.gemm]
+    B, N = args.batch, args.points
     torch.manual_seed(0)
-    model = LineRefineNet().to(dev).train()
+    if args.stub:
+        from pointnet_refine_amd.synth import synthetic_batch
+        model = StubNet.build().train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        step = TrainStep(model, opt, decoder_chunk=None, world_size=world,
+                         loss_fn=lambda out, target, denom=None: (out - target.unsqueeze(0)).abs().sum()
+                         / (out.numel() if denom is None else denom))
+        ctx, noisy, target = synthetic_batch(B, N, dev, seed=1234 + rank)
+    else:
+        from pointnet_refine_amd import _lib
+        from pointnet_refine_amd.model import LineRefineNet
+        from pointnet_refine_amd.synth import synthetic_batch
+        lib = _lib.lib()
+        _lib.check(lib.prh_set_gemm_mode(mode), "prh_set_gemm_mode")
+        model = LineRefineNet().to(dev).train()
+        # optimizer=None: the library's flat-buffer Adam (same update as torch.optim.Adam(lr=1e-3),
+        # tests/test_loss_adam_gpu.py), one launch per step; the loss is the fused HIP L1 either way
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3) if args.torch_adam else None
+        step = TrainStep(model, opt, decoder_chunk=args.decoder_chunk, world_size=world, graph=args.graph)
+        ctx, noisy, target = synthetic_batch(B, N, dev, seed=1234 + rank)
     if launched:
         for p in model.parameters():                 # same start on every rank (DDP does this)
             dist.broadcast(p.data, 0)
-    # optimizer=None: the library's flat-buffer Adam (same update as torch.optim.Adam(lr=1e-3),
-    # tests/test_loss_adam_gpu.py), one launch per step; the loss is the fused HIP L1 either way
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3) if args.torch_adam else None
-    step = TrainStep(model, opt, decoder_chunk=args.decoder_chunk, world_size=world, graph=args.graph)
-
-    B, N = args.batch, args.points
-    ctx, noisy, target = synthetic_batch(B, N, dev, seed=1234 + rank)
 
     def sync():
         if launched:
-            dist.barrier(device_ids=[local_rank])
-        torch.cuda.synchronize(dev)
+            if args.stub:
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[local_rank])
+        if not args.stub:
+            torch.cuda.synchronize(dev)
+
+    def mem_gib():
+        return 0.0 if args.stub else torch.cuda.max_memory_allocated(dev) / 2**30
 
     for i in range(args.warmup):
         loss = step(ctx, noisy, target)
         if rank == 0:
-            torch.cuda.synchronize(dev)
-            log(f"warmup {i} done, loss {float(loss):.5f}, mem {torch.cuda.max_memory_allocated(dev) / 2**30:.1f} GiB")
+            if not args.stub:
+                torch.cuda.synchronize(dev)
+            log(f"warmup {i} done, loss {float(loss):.5f}, mem {mem_gib():.1f} GiB")
     sync()
-    lib.prh_profile_enable(4096)
+    # live per-launch HIP events: room for every GEMM launch of the timed region (about 500 per
+    # step and decoder chunk pair); if it still fills up only whole steps are counted
+    cap = 0
+    marks = []
+    if lib is not None:
+        chunks = max(1, -(-B // max(1, args.decoder_chunk)))
+        cap = min(262144, (args.steps + 1) * (400 + 300 * chunks))
+        lib.prh_profile_enable(cap)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step(ctx, noisy, target)
+        if lib is not None:
+            marks.append(lib.prh_profile_count())
     sync()
     dt = time.perf_counter() - t0
     if rank == 0:
@@ -189,85 +370,136 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    if args.graph:
-        # the library's per-launch events are not recorded inside a replayed graph: one eager
-        # step after the timed region supplies the per-kernel figures of the roofline object
-        lib.prh_profile_reset()
-        step.use_graph = False
-        step.close()                     # the graph's pool and an eager step do not fit together at B=4096
-        ops.release_workspaces()
-        torch.cuda.empty_cache()
-        step(ctx, noisy, target)
-        sync()
-    # per-kernel live durations (HIP events on the launch stream)
-    agg = {}
-    name = C.create_string_buffer(64)
-    ms, fl, by = C.c_float(), C.c_double(), C.c_double()
-    for i in range(lib.prh_profile_count()):
-        lib.prh_profile_read(i, name, 64, C.byref(ms), C.byref(fl), C.byref(by))
-        a = agg.setdefault(name.value.decode(), [0, 0.0, fl.value, by.value])
-        a[0] += 1
-        a[1] += ms.value
-    lib.prh_profile_enable(0)
-    hip_ms = sum(a[1] for a in agg.values())
-    if rank == 0 and args.kernels > 0:
-        for k, (c, t, f, _) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:args.kernels]:
-            print(f"[bench] {k:44s} x{c:3d} {t / c:8.3f} ms  {f / (t / c * 1e-3) / 1e12:7.1f} TF", file=sys.stderr)
-    dom = max(agg.items(), key=lambda kv: kv[1][1])
-    dname, (cnt, tot_ms, flops, bytes_) = dom
-    avg_ms = tot_ms / cnt
-    achieved = flops / (avg_ms * 1e-3) / 1e12
-    # achieved = ALGORITHMIC fp32 FLOPs (2*M*N*K) / live launch time.  Peak of the core the
-    # kernel runs on: the exact fp32 MFMA pipe, or - for the split cores, which issue 6 bf16
-    # MFMA products per fp32-accurate MAC - the dense bf16 MFMA peak divided by 6.
-    split = "_s3" in dname
-    one = "_b1" in dname
-    h2 = "_h2" in dname
-    products = SPLIT_PRODUCTS if split else (SPLIT16_PRODUCTS if h2 else 1)
-    peak = BF16_MFMA_PEAK_TFLOPS / products if (split or h2 or one) else FP32_MFMA_PEAK_TFLOPS
-    roofline = {"bound": "mfma", "kernel": dname, "achieved": round(achieved, 2),
-                "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                "peak_basis": ("2500 TF dense bf16 MFMA / 6 products per fp32-accurate MAC (3-plane bf16 split)"
-                               if split else ("2500 TF dense fp16 MFMA / 3 products per fp32-accurate MAC "
-                                              "(2 scaled fp16 planes)" if h2 else
-                                              ("2500 TF dense bf16 MFMA" if one else
-                                               "157.3 TF fp32 MFMA (v_mfma_f32_32x32x2_f32)"))),
-                "issued_mfma_tflops": round(achieved * products, 1),
-                "vs_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                "traffic": pmc_traffic(dname, B, N, lib.prh_get_gemm_mode()),
-                "traffic_source": f"profiles/{PMC_TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE x2, WRITE_SIZE)",
-                "algorithmic_bytes": bytes_,
-                "avg_launch_ms": round(avg_ms, 4), "launches": cnt,
-                "algorithmic_gbs": round(bytes_ / (avg_ms * 1e-3) / 1e9, 1),
-                "hbm_frac": round(bytes_ / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "hip_gemm_ms_per_step": round(hip_ms / args.steps, 2)}
+    roofline = None
+    if lib is not None:
+        if args.graph:
+            # the library's per-launch events are not recorded inside a replayed graph: one eager
+            # step after the timed region supplies the per-kernel figures of the roofline object
+            from pointnet_refine_amd import ops
+            lib.prh_profile_reset()
+            step.use_graph = False
+            step.close()                 # the graph's pool and an eager step do not fit together at B=4096
+            ops.release_workspaces()
+            torch.cuda.empty_cache()
+            step(ctx, noisy, target)
+            sync()
+            marks = [lib.prh_profile_count()]
+        # whole steps whose launches were all recorded
+        covered = [m for m in marks if m < cap]
+        n_steps_prof = len(covered)
+        n_rec = covered[-1] if covered else 0
+        agg = {}
+        name = C.create_string_buffer(64)
+        ms, fl, by = C.c_float(), C.c_double(), C.c_double()
+        for i in range(n_rec):
+            lib.prh_profile_read(i, name, 64, C.byref(ms), C.byref(fl), C.byref(by))
+            a = agg.setdefault(name.value.decode(), [0, 0.0, fl.value, by.value])
+            a[0] += 1
+            a[1] += ms.value
+        lib.prh_profile_enable(0)
+        hip_ms = sum(a[1] for a in agg.values())
+        if rank == 0 and args.kernels > 0:
+            for k, (c, t, f, _) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:args.kernels]:
+                print(f"[bench] {k:44s} x{c:4d} {t / c:8.3f} ms  {f / (t / c * 1e-3) / 1e12:7.1f} TF", file=sys.stderr)
+        if agg:
+            # dominant = the kernel (name incl. its GEMM shape) with the most time in the timed region
+            dname, (cnt, tot_ms, flops, bytes_) = max(agg.items(), key=lambda kv: kv[1][1])
+            avg_ms = tot_ms / cnt
+            achieved = flops / (avg_ms * 1e-3) / 1e12
+            # achieved = ALGORITHMIC FLOPs (2*M*N*K) / live launch time.  Peak of the core the
+            # kernel runs on: the exact fp32 MFMA pipe, or the dense 16-bit MFMA peak divided by
+            # the products the core issues per algorithmic MAC.
+            on_fp32_core = not any(t in dname for t in ("_s3", "_b1", "_h2", "_b16"))
+            products, peak16, basis, _ = MODE_INFO[mode]
+            if on_fp32_core:
+                products, peak16, basis = 1, FP32_MFMA_PEAK_TFLOPS, MODE_INFO[0][2]
+            peak = peak16 / products
+            traffic, tfile = pmc_traffic(dname, B, N, mode)
+            sf = step_flops(B, N)
+            s_ach = sf / (dt / args.steps) / 1e12
+            mode_peak = MODE_INFO[mode][1] / MODE_INFO[mode][0]
+            roofline = {"bound": "mfma", "kernel": dname, "achieved": round(achieved, 2),
+                        "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                        "peak_basis": basis,
+                        "issued_mfma_tflops": round(achieved * products, 1),
+                        "vs_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                        "traffic": traffic,
+                        "traffic_source": (f"profiles/{tfile} (rocprofv3 --pmc FETCH_SIZE x2, WRITE_SIZE)"
+                                           if tfile else None),
+                        "algorithmic_bytes": bytes_,
+                        "avg_launch_ms": round(avg_ms, 4), "launches": cnt,
+                        "launches_per_step": round(cnt / max(1, n_steps_prof), 2),
+                        "algorithmic_gbs": round(bytes_ / (avg_ms * 1e-3) / 1e9, 1),
+                        "hbm_frac": round(bytes_ / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "profiled_steps": n_steps_prof,
+                        "hip_gemm_ms_per_step": round(hip_ms / max(1, n_steps_prof), 2),
+                        "step": {"flops": sf, "achieved_tflops": round(s_ach, 1),
+                                 "peak": round(mode_peak, 1), "frac": round(s_ach / mode_peak, 4),
+                                 "basis": "whole training step: 3 x (8,013,952*N + 12,482,432*32) FLOP per "
+                                          "segment (SURVEY 8d) / step time, against the peak of this GEMM mode"}}
+
+    parity = None
+    if lib is not None and not args.no_parity and not args.graph:
+        try:
+            parity = parity_check(step, model, (ctx, noisy, target), lib, mode, dev)
+            exact = mode in (0, 1, 3)
+            gate = {"out": 1e-4 if exact else 5e-2, "grad_rel_l2": 2e-3 if exact else None}
+            parity["gate"] = gate
+            parity["ok"] = bool(parity["out_max_abs_vs_exact_fp32"] <= gate["out"] and
+                                (gate["grad_rel_l2"] is None or parity["worst_grad_rel_l2"] <= gate["grad_rel_l2"]))
+            for k in ("out_max_abs_vs_exact_fp32", "worst_grad_rel_l2", "all_grads_rel_l2"):
+                parity[k] = float(f"{parity[k]:.4g}")
+            if rank == 0:
+                log(f"parity at B={B}, N={N}: {parity}")
+        except torch.cuda.OutOfMemoryError as e:       # report, never hide
+            parity = {"ok": None, "error": f"parity step did not fit: {str(e)[:120]}"}
+    parity_failed = bool(parity is not None and parity.get("ok") is False)
+    if launched and parity is not None:
+        f = torch.tensor([1.0 if parity_failed else 0.0], device=dev)
+        dist.all_reduce(f, op=dist.ReduceOp.MAX)
+        parity_failed = bool(f.item() > 0)
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
+        backend = "gloo, CPU stub" if args.stub else "RCCL gradient all-reduce"
         line = {
-            "metric": "lane segments/sec (fwd+bwd) at B=4096,N=1024; HBM GB/s vs roofline",
+            "metric": ("STUB (launcher self-test, not a measurement) " if args.stub else "") +
+                      "lane segments/sec (fwd+bwd) at B=4096,N=1024; HBM GB/s vs roofline",
             "value": round(world * B * args.steps / dt, 2), "unit": "segments/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {0: "f32", 1: "f32 (large GEMMs: 3xbf16-split MFMA, fp32 accumulate)",
-                      2: "bf16 MFMA operands, fp32 accumulate and storage (reduced precision)",
-                      3: "f32 (large GEMMs: 2xfp16-split MFMA, 3 products, fp32 accumulate)"}[lib.prh_get_gemm_mode()],
+            "vs_baseline": None, "dtype": "f32 (CPU stub)" if args.stub else MODE_INFO[mode][3],
             "data": "synthetic",
-            "config": {"workload": f"LineRefineNet training step (fwd + deep-supervision L1 + bwd + Adam), "
-                                   f"B={B}/GPU, N={N}, M=32, C=4, fp32",
+            "config": {"workload": ("CPU stand-in step, " if args.stub else "") +
+                                   f"LineRefineNet training step (fwd + deep-supervision L1 + bwd + Adam), "
+                                   f"B={B}/GPU, N={N}, M=32, C=4",
                        "global_batch": world * B, "points": N,
-                       "parallelism": f"dp{world}" + (" (RCCL gradient all-reduce)" if world > 1 else ""),
+                       "parallelism": f"dp{world}" + (f" ({backend})" if world > 1 else ""),
                        "decoder_chunk": args.decoder_chunk},
             "loss": round(float(loss), 6),
-            "max_mem_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1),
-            "roofline": roofline,
+            "max_mem_gb": round(mem_gib(), 1),
         }
+        if roofline is not None:
+            line["roofline"] = roofline
+        if parity is not None:
+            line["parity"] = parity
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, args.cpu_batch)
         print(json.dumps(line), flush=True)
     if launched:
         dist.destroy_process_group()
+    if parity_failed:
+        log("PARITY GATE FAILED at the benchmark size - see the parity object of the line above")
+        return 4
+    return 0
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return launch_ranks(args)
+    return run(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -54,9 +54,12 @@ class FlatGrads:
         # runs whenever a process group exists (also at world_size 1 under torchrun, so the
         # single-GPU launch exercises the same RCCL calls as the 8-GPU one)
         if dist.is_available() and dist.is_initialized():
+            n = dist.get_world_size(group)
+            if world_size not in (None, 1, n):
+                raise RuntimeError(f"TrainStep: world_size={world_size} disagrees with the process group ({n} ranks)")
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-            if world_size > 1:
-                self.flat.div_(world_size)
+            if n > 1:                  # the mean DDP takes (train_dist.py:147), whatever the caller passed
+                self.flat.div_(n)
 
 
 class FlatBuffers:
@@ -145,6 +148,8 @@ class TrainStep:
         self.model = model
         self.loss_fn = loss_fn if loss_fn is not None else deep_supervision_l1
         self.geometry = None
+        self.keep_out = False         # True: forward_backward stashes the detached predictions in last_out
+        self.last_out = None
         self.use_graph, self._graph, self._static, self._seed = bool(graph), None, None, None
         self.chunk = decoder_chunk
         self.world, self.group = world_size, group
@@ -169,6 +174,8 @@ class TrainStep:
             out = m(context, noisy_line)
             loss = self._loss(out, target, float(out.numel()), float(target.numel() // 3))
             loss.backward()
+            if self.keep_out:
+                self.last_out = out.detach()
             return loss.detach()
         # encoder side at full batch (BatchNorm statistics span the whole per-rank batch)
         memory = m.encode_context(context)
@@ -178,6 +185,7 @@ class TrainStep:
         mem_d, tgt_d = memory.detach(), tgt0.detach()
         total = torch.zeros((), device=context.device, dtype=torch.float32)
         denom = float(6 * B * noisy_line.shape[1] * noisy_line.shape[2])
+        outs = [] if self.keep_out else None
         for s in range(0, B, self.chunk):
             e = min(s + self.chunk, B)
             mem_c = mem_d[s:e].requires_grad_()
@@ -188,8 +196,12 @@ class TrainStep:
             d_memory[s:e] = mem_c.grad
             d_tgt0[s:e] = tgt_c.grad
             total += loss_c.detach()
+            if outs is not None:
+                outs.append(out.detach())
             del out, loss_c, mem_c, tgt_c
         torch.autograd.backward([memory, tgt0], [d_memory, d_tgt0])
+        if outs is not None:
+            self.last_out = torch.cat(outs, dim=1)
         return total
 
     def close(self):
@@ -221,12 +233,21 @@ class TrainStep:
             self.geometry = torch.zeros(2, dtype=torch.float32, device=dev)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
+        # the warm-up passes are train-mode forwards: they would push this batch into every
+        # BatchNorm running statistic (and num_batches_tracked) twice more than an eager step
+        # does - snapshot the buffers and put them back, so graph and eager runs checkpoint alike
+        bufs = [b for b in self.model.buffers()]
+        saved = [b.detach().clone() for b in bufs]
         with torch.cuda.stream(side):
             for _ in range(2):                      # allocations, workspaces, lazy initialisation
                 self._seed.add_(1)
                 self.grads.flat.zero_()
                 self.forward_backward(*self._static)
+            with torch.no_grad():
+                for b, s0 in zip(bufs, saved):
+                    b.copy_(s0)
         torch.cuda.current_stream(dev).wait_stream(side)
+        del saved
         # the capture allocates from a private pool, which cannot reuse what the warm-up left in
         # the default pool - its cached blocks and the per-stream scratch buffers of ops._ws
         # (tens of GB at B=4096): hand them back first, or the two pools together exceed 288 GB

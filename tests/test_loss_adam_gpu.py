@@ -159,7 +159,7 @@ def test_graph_captured_step_matches_eager_step():
     from pointnet_refine_amd.train_step import TrainStep
     ctx, noisy, target = synthetic_batch(8, 256, torch.device("cuda", 0))
     try:
-        losses = {}
+        losses, buffers = {}, {}
         for graph in (False, True):
             torch.manual_seed(21)
             m = LineRefineNet().cuda().train()
@@ -170,8 +170,17 @@ def test_graph_captured_step_matches_eager_step():
                     mod.dropout = 0.0
             step = TrainStep(m, decoder_chunk=4, graph=graph)
             losses[graph] = [float(step(ctx, noisy, target)) for _ in range(4)]
+            buffers[graph] = {k: v.detach().clone() for k, v in m.named_buffers()}
         for a, b in zip(losses[False], losses[True]):
             assert abs(a - b) < 2e-4 * max(a, 1e-3), (losses[False], losses[True])
+        # checkpoints of graph and eager runs agree: the capture's warm-up passes must not leak
+        # into the BatchNorm running statistics or num_batches_tracked
+        for k, v in buffers[False].items():
+            w = buffers[True][k]
+            if v.is_floating_point():
+                assert float((v - w).abs().max()) <= 1e-3 * float(v.abs().max()) + 1e-5, k
+            else:
+                assert int(v) == int(w) == 4, (k, int(v), int(w))
         # dropout on: the same weights and inputs give different losses on consecutive replays
         torch.manual_seed(22)
         m = LineRefineNet().cuda().train()
