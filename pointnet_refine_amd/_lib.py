@@ -15,8 +15,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 # PRH_LIB_PATH: load an alternative build of the same library (kernel-tuning experiments)
 LIB_PATH = os.environ.get("PRH_LIB_PATH") or os.path.join(_HERE, "libpointnet_refine_hip.so")
-_SOURCES = [os.path.join(_HERE, "csrc", f)
-            for f in ("prh_lib.hip", "prh_gemm.hpp", "prh_gemm_s3.hpp", "prh_gemm_h2.hpp", "prh_attn.hpp", "prh_kernels.hpp")]
+_CSRC = os.path.join(_HERE, "csrc")
+# every file of csrc/ counts for staleness (prh_lib.hip is the one translation unit; it includes the rest)
+_SOURCES = [os.path.join(_CSRC, "prh_lib.hip")] + sorted(
+    os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hpp", ".h", ".hip")) and f != "prh_lib.hip")
 _HEADER = os.path.join(_ROOT, "include", "pointnet_refine_hip.h")
 
 PRH_MAX_LAYERS = 8

@@ -69,7 +69,16 @@ def resample_polylines_device(raw_lines, num_points, device):
 def build_contexts_resampled(cloud, dense, line, num_context_points=1024, crop_radius=0.3,
                              decay_scale=2.0, seed=0, max_candidates=None, return_weights=False):
     """cloud (P,4), dense (L,D,3), line (L,M,3) float32 CUDA tensors ->
-    context (L,N,4) centred on each line's mean, counts (L,) int32 [, weights (L,max_candidates)]."""
+    context (L,N,4) centred on each line's mean, counts (L,) int32 [, weights (L,max_candidates)].
+
+    The reference samples from EVERY point of a line's tube (src/dataset.py:86-130).  The kernels
+    compact a tube's points into a candidate buffer of `max_candidates` slots per line; with
+    max_candidates=None (default) the buffer starts at max(4*N, 8192) slots and, when the largest
+    tube of the call turns out to hold more points than that (dense LiDAR at the training radius),
+    the call is repeated with the buffer sized from the true counts - the draw is then identical
+    to what a large enough buffer gives in the first place (same seed, same candidates in cloud
+    order).  An explicit max_candidates is taken as is and a RuntimeWarning reports any tube it
+    truncated."""
     for t, name in ((cloud, "cloud"), (dense, "dense"), (line, "line")):
         if not (t.is_cuda and t.dtype == torch.float32):
             raise RuntimeError(f"build_contexts: {name} must be a float32 CUDA tensor (there is no CPU fallback)")
@@ -81,23 +90,36 @@ def build_contexts_resampled(cloud, dense, line, num_context_points=1024, crop_r
     dev = cloud.device
     n_lines, n = dense.shape[0], int(num_context_points)
     npts = cloud.shape[0]
-    if max_candidates is None:
+    auto = max_candidates is None
+    if auto:
         max_candidates = max(4 * n, 8192)
     max_candidates = max(int(max_candidates), n + 1)
     out = torch.empty((n_lines, n, 4), dtype=torch.float32, device=dev)
     counts = torch.empty((n_lines,), dtype=torch.int32, device=dev)
-    weights = torch.zeros((n_lines, max_candidates), dtype=torch.float32, device=dev) if return_weights else None
     if n_lines == 0:
+        weights = torch.zeros((0, max_candidates), dtype=torch.float32, device=dev) if return_weights else None
         return (out, counts, weights) if return_weights else (out, counts)
     lib = L.lib()
-    nb = lib.prh_context_workspace_bytes(npts, n_lines, max_candidates)
-    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else None
-    L.check(lib.prh_context_build(p(cloud), npts, p(dense), dense.shape[1], p(line), line.shape[1], n_lines,
-                                  float(crop_radius), float(decay_scale), n, max_candidates,
-                                  C.c_ulonglong(int(seed) & 0xFFFFFFFFFFFFFFFF), p(out), p(counts), p(weights),
-                                  p(ws), nb, dev.index, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
-            "prh_context_build")
+    while True:
+        weights = torch.zeros((n_lines, max_candidates), dtype=torch.float32, device=dev) if return_weights else None
+        nb = lib.prh_context_workspace_bytes(npts, n_lines, max_candidates)
+        ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        L.check(lib.prh_context_build(p(cloud), npts, p(dense), dense.shape[1], p(line), line.shape[1], n_lines,
+                                      float(crop_radius), float(decay_scale), n, max_candidates,
+                                      C.c_ulonglong(int(seed) & 0xFFFFFFFFFFFFFFFF), p(out), p(counts), p(weights),
+                                      p(ws), nb, dev.index, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                "prh_context_build")
+        largest = int(counts.max().item())           # one small read-back per scene
+        if largest <= max_candidates:
+            break
+        if not auto:
+            import warnings
+            warnings.warn(f"build_contexts: a tube holds {largest} points but max_candidates={max_candidates}; "
+                          f"its context was drawn from the first {max_candidates} points in cloud order only "
+                          "(pass max_candidates=None to size the buffer from the counts)", RuntimeWarning)
+            break
+        max_candidates = largest                     # true counts are known now: one exact repeat
     return (out, counts, weights) if return_weights else (out, counts)
 
 

@@ -44,10 +44,11 @@ def load_pcd_data(pcd_path):
             if len(payload) == n_points * dt.itemsize:
                 rec = np.frombuffer(payload, dtype=dt)
                 return np.column_stack((rec["x"], rec["y"], rec["z"], rec["intensity"].astype(np.float32)))
-        print(f"Unknown binary format for {pcd_path}, bytes={len(payload)}, points={n_points}")
+        print(f"[pointnet_refine_amd.io] {pcd_path}: {len(payload)} payload bytes match neither the 16-byte "
+              f"nor the 14-byte record layout for {n_points} points; returning an empty cloud")
         return np.zeros((0, 4), dtype=np.float32)
     except Exception as e:                       # the reference reports and carries on
-        print(f"Error loading {pcd_path}: {e}")
+        print(f"[pointnet_refine_amd.io] could not read {pcd_path} ({type(e).__name__}: {e}); returning an empty cloud")
         return np.zeros((0, 4), dtype=np.float32)
 
 
@@ -79,6 +80,8 @@ def refine_scene(model, pcd_points, raw_lines, num_line_points=32, num_context_p
     dev = next(model.parameters()).device
     cloud = pcd_points if torch.is_tensor(pcd_points) else torch.from_numpy(np.ascontiguousarray(pcd_points, dtype=np.float32))
     cloud = cloud.to(dev, torch.float32)
+    if cloud.dim() == 2 and cloud.shape[1] > 4:
+        cloud = cloud[:, :4]                      # ASCII PCDs may carry extra fields: x y z intensity come first
     if len(raw_lines) == 0:
         return np.zeros((0, num_line_points, 3)), np.zeros((0, num_line_points, 3))
     was_training = model.training
@@ -97,23 +100,44 @@ def refine_scene(model, pcd_points, raw_lines, num_line_points=32, num_context_p
 
 
 class SceneSampleStream:
-    """Training samples straight from scene files, one batch per scene, built on the GPU.
+    """Training samples straight from scene files, built on the GPU, sharded over ranks.
 
     The reference's ``LaneRefineDataset`` (src/dataset.py:132-253) builds ONE sample per
     ``__getitem__`` in DataLoader workers: JSON parse, KDTree crop of the whole cloud, numpy
-    sampling.  Here a scene's cloud goes to the device once and the contexts of ALL its samples
-    (every noisy candidate of every item, :152-166) come from one ``prh_context_build`` call.
-    Same constructor arguments and the same per-sample tensors: ``context (N,4)`` centred on the
-    noisy line's mean with raw intensity, ``noisy_line (M,3)`` centred, ``target_offset (M,3)`` =
-    resampled ground truth - resampled noisy line (:206-207,241).  Iterating yields dicts of
-    CUDA tensors with a leading sample dimension; ``len()`` is the number of samples."""
+    sampling; ``train_dist.py:129-140`` feeds it through ``DistributedSampler(shuffle=True)`` and a
+    ``DataLoader(batch_size=32)``.  Here a scene's cloud goes to the device once and the contexts
+    of all of THIS RANK's samples of that scene (noisy candidates of its items, :152-166) come
+    from one ``prh_context_build`` call.  Same constructor arguments and the same per-sample
+    tensors: ``context (N,4)`` centred on the noisy line's mean with raw intensity, ``noisy_line
+    (M,3)`` centred, ``target_offset (M,3)`` = resampled ground truth - resampled noisy line
+    (:206-207,241).
+
+    Sharding and order (the DistributedSampler + DataLoader semantics, per scene so that a cloud
+    is uploaded once): every epoch the scene order and each scene's sample order are permuted
+    from ``(seed, epoch)`` - identically on every rank - and a scene's samples are dealt
+    round-robin to the ranks, padded by wrap-around so that every rank gets the same number
+    (DistributedSampler's padding).  A rank's samples are pooled over ``mix_scenes`` scenes,
+    shuffled, and cut into batches of ``batch_size``: all ranks yield the same number of
+    batches, so a gradient all-reduce per batch cannot dead-lock.  ``batch_size=None`` keeps one
+    batch per scene.  ``rank`` / ``world_size`` default to the initialised process group (else
+    0 / 1).  Iterating yields dicts of CUDA tensors with a leading sample dimension; ``len()`` is
+    the number of samples this rank sees per epoch."""
 
     def __init__(self, data_root, num_line_points=32, num_context_points=2048, crop_radius=4.0,
-                 decay_scale=2.0, split="train", device="cuda", seed=0):
+                 decay_scale=2.0, split="train", device="cuda", seed=0, batch_size=None, shuffle=True,
+                 rank=None, world_size=None, mix_scenes=4, drop_last=False):
         import os
+        import torch.distributed as dist
         self.num_line_points, self.num_context_points = num_line_points, num_context_points
         self.crop_radius, self.decay_scale = crop_radius, decay_scale
         self.device, self.seed, self.split = torch.device(device), seed, split
+        grouped = dist.is_available() and dist.is_initialized()
+        self.rank = int(rank if rank is not None else (dist.get_rank() if grouped else 0))
+        self.world = int(world_size if world_size is not None else (dist.get_world_size() if grouped else 1))
+        if not 0 <= self.rank < self.world:
+            raise ValueError(f"SceneSampleStream: rank {self.rank} outside world_size {self.world}")
+        self.batch_size, self.shuffle = batch_size, bool(shuffle)
+        self.mix_scenes, self.drop_last = max(1, int(mix_scenes)), bool(drop_last)
         self.scenes = []                       # (pcd_path, json_path, [(item_idx, noise_idx), ...])
         for name in sorted(f for f in os.listdir(data_root) if f.endswith(".json")):
             json_path = os.path.join(data_root, name)
@@ -129,22 +153,73 @@ class SceneSampleStream:
                 self.scenes.append((pcd_path, json_path, pairs))
         self.epoch = 0
 
+    def _share(self, n):
+        return -(-n // self.world)             # samples of an n-sample scene each rank takes (padded)
+
     def __len__(self):
-        return sum(len(s[2]) for s in self.scenes)
+        return sum(self._share(len(s[2])) for s in self.scenes)
 
     def set_epoch(self, epoch):
         self.epoch = int(epoch)
 
-    def __iter__(self):
+    def _plan(self):
+        """[(scene index, this rank's (item, candidate) pairs)] for the current epoch."""
+        g = np.random.default_rng([int(self.seed) & 0x7FFFFFFF, self.epoch])
+        order = g.permutation(len(self.scenes)) if self.shuffle else np.arange(len(self.scenes))
+        plan = []
+        for si in order:
+            pairs = self.scenes[si][2]
+            idx = g.permutation(len(pairs)) if self.shuffle else np.arange(len(pairs))
+            per = self._share(len(pairs))
+            idx = np.resize(idx, per * self.world)                 # wrap-around padding
+            plan.append((int(si), [pairs[j] for j in idx[self.rank::self.world]]))
+        return plan
+
+    def _scene_samples(self, si, pairs):
         from .context import resample_polyline
-        for si, (pcd_path, json_path, pairs) in enumerate(self.scenes):
-            cloud = torch.from_numpy(load_pcd_data(pcd_path)).to(self.device, torch.float32)
-            items = load_scene_items(json_path)
-            raw_noisy = [items[i]["noisy_candidates"][k] for i, k in pairs]
-            gt = np.stack([resample_polyline(items[i]["position"], self.num_line_points) for i, _ in pairs])
-            ctx, noisy_c, centres, counts = build_contexts(
-                cloud.reshape(-1, 4), raw_noisy, self.num_line_points, self.num_context_points, self.crop_radius,
-                self.decay_scale, seed=(self.seed * 1000003 + self.epoch) * 65537 + si)
-            gt_c = torch.from_numpy(gt).to(self.device, torch.float32) - centres[:, None, :]
-            yield {"context": ctx, "noisy_line": noisy_c, "target_offset": gt_c - noisy_c,
-                   "points_in_tube": counts, "scene": pcd_path}
+        pcd_path, json_path, _ = self.scenes[si]
+        cloud = torch.from_numpy(np.atleast_2d(load_pcd_data(pcd_path))[:, :4].astype(np.float32, copy=False))
+        cloud = cloud.to(self.device, torch.float32).contiguous()
+        items = load_scene_items(json_path)
+        raw_noisy = [items[i]["noisy_candidates"][k] for i, k in pairs]
+        gt = np.stack([resample_polyline(items[i]["position"], self.num_line_points) for i, _ in pairs])
+        ctx, noisy_c, centres, counts = build_contexts(
+            cloud, raw_noisy, self.num_line_points, self.num_context_points, self.crop_radius, self.decay_scale,
+            seed=((self.seed * 1000003 + self.epoch) * 65537 + si) * 1021 + self.rank)
+        gt_c = torch.from_numpy(gt).to(self.device, torch.float32) - centres[:, None, :]
+        return {"context": ctx, "noisy_line": noisy_c, "target_offset": gt_c - noisy_c, "points_in_tube": counts}
+
+    def __iter__(self):
+        plan = self._plan()
+        if self.batch_size is None:
+            for si, pairs in plan:
+                if pairs:
+                    d = self._scene_samples(si, pairs)
+                    d["scene"] = self.scenes[si][0]
+                    yield d
+            return
+        keys = ("context", "noisy_line", "target_offset", "points_in_tube")
+        g = torch.Generator().manual_seed(((int(self.seed) * 7919 + self.epoch) * 31 + 17) & 0x7FFFFFFF)
+        pool = None
+        bs = int(self.batch_size)
+
+        def emit(final):
+            nonlocal pool
+            while pool is not None and (pool[keys[0]].shape[0] >= bs or (final and pool[keys[0]].shape[0] > 0
+                                                                          and not self.drop_last)):
+                yield {k: pool[k][:bs] for k in keys}
+                pool = {k: pool[k][bs:] for k in keys} if pool[keys[0]].shape[0] > bs else None
+
+        for j, (si, pairs) in enumerate(plan):
+            if pairs:
+                d = self._scene_samples(si, pairs)
+                pool = d if pool is None else {k: torch.cat([pool[k], d[k]]) for k in keys}
+            if (j + 1) % self.mix_scenes == 0 and pool is not None:
+                if self.shuffle:                 # same permutation on every rank: equal pool sizes
+                    perm = torch.randperm(pool[keys[0]].shape[0], generator=g).to(self.device)
+                    pool = {k: pool[k][perm] for k in keys}
+                yield from emit(False)
+        if pool is not None and self.shuffle:
+            perm = torch.randperm(pool[keys[0]].shape[0], generator=g).to(self.device)
+            pool = {k: pool[k][perm] for k in keys}
+        yield from emit(True)

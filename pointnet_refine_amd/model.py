@@ -7,16 +7,23 @@ entries, names/shapes/dtypes of ``/root/reference/src/model.py``), so the refere
 LineRefineNet`` and a strict ``load_state_dict`` of a reference checkpoint succeeds.
 
 The submodules (``nn.Conv1d``, ``nn.BatchNorm1d``, ``nn.Linear`` ...) exist as PARAMETER
-CONTAINERS with the reference's names and default initialisation; the arithmetic of the
-accelerated rows (a1-a6) does not go through them but through
-``ops.py`` -> C ABI -> hand-written gfx950 kernels:
+CONTAINERS with the reference's names and default initialisation; the arithmetic of every
+row of SURVEY.md section 8a does not go through them but through ``ops.py`` -> C ABI ->
+hand-written gfx950 kernels:
 
-  a1-a4  MultiScalePointNetEncoder   ops.encoder        (src/model.py:39-62)
-  a5     context_proj                ops.linear         (src/model.py:147,194)
-  a6     point_mlp                   ops.mlp_stack      (src/model.py:150-159,200-201)
+  a1-a4  MultiScalePointNetEncoder   ops.encoder / ops.encoder_eval_fused   (src/model.py:39-62)
+  a5     context_proj                ops.linear                             (src/model.py:147,194)
+  a6     point_mlp                   ops.mlp_stack                          (src/model.py:150-159,200-201)
+  a7     regression heads            ops.linear (ReLU epilogue) + ops.linear_small   (:172-179,220)
+  a9     PositionalEncoding          ops.pos_hidden + ops.linear (residual epilogue) (:64-75)
+  a10    DETR decoder layers         ops.linear, ops.attention / attention_block,
+                                     ops.add_dropout_layernorm                       (:77-135)
 
-Rows a7-a10 (regression heads, positional encoding, DETR decoder) run on stock
-PyTorch-ROCm modules for now (SURVEY.md section 8f "next").
+What is left to PyTorch is plumbing: the autograd graph, the FFN dropout, the elementwise adds
+of the positional embeddings and ``torch.stack``.  The ``_lin`` / ``_attn`` / ``_add_norm``
+helpers keep a stock-PyTorch branch for shapes the kernels do not take (widths that are not
+multiples of 4, heads that are not 32 wide); the default model never takes it, and
+``FALLBACKS`` counts every time it is taken (tests/test_model_gpu.py asserts it stays empty).
 """
 from __future__ import annotations
 
@@ -25,6 +32,15 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+
+
+# name -> number of times a stock-PyTorch branch ran instead of a HIP kernel (stays empty for
+# the default LineRefineNet; see the module docstring)
+FALLBACKS = {}
+
+
+def _fell_back(name):
+    FALLBACKS[name] = FALLBACKS.get(name, 0) + 1
 
 
 def _bn_buffers(bn: nn.BatchNorm1d):
@@ -38,6 +54,7 @@ def _attn(q, k, v, heads, dropout_p):
     if q.is_cuda and C == heads * 32 and heads % 4 == 0 and q.dtype == torch.float32:
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if dropout_p > 0.0 else 0
         return ops.attention(q, k, v, heads, dropout_p, seed)
+    _fell_back("attention")
     N = k.shape[1]
     qh = q.reshape(B, M, heads, C // heads).transpose(1, 2)
     kh = k.reshape(B, N, heads, C // heads).transpose(1, 2)
@@ -51,6 +68,7 @@ def _add_norm(x, r, norm, drop, training):
     the stock modules otherwise."""
     if x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == 256 and norm.elementwise_affine:
         return ops.add_dropout_layernorm(x, r, norm, drop.p if training else 0.0)
+    _fell_back("add_norm")
     return norm(x + drop(r))
 
 
@@ -60,6 +78,7 @@ def _lin(x, weight, bias):
     torch.nn.functional.linear."""
     if x.is_cuda and weight.shape[0] % 4 == 0 and weight.shape[1] % 4 == 0:
         return ops.linear(x, weight, bias)
+    _fell_back("linear")
     return F.linear(x, weight, bias)
 
 
@@ -131,6 +150,7 @@ class PositionalEncoding(nn.Module):
             # is HBM work); Linear(H,H) (+ resid) on the HIP GEMM cores
             h = ops.pos_hidden(xyz, l0.weight, l0.bias)
             return ops.linear(h, l2.weight, l2.bias, None, False, resid)
+        _fell_back("pos_hidden")
         h = F.relu(F.linear(xyz, l0.weight, l0.bias))
         y = _lin(h, l2.weight, l2.bias)
         return y if resid is None else y + resid
@@ -194,6 +214,7 @@ class DetrTransformerDecoderLayer(nn.Module):
         if self.activation is F.relu and tgt.is_cuda:      # ReLU rides on the GEMM epilogue
             hid = ops.linear(tgt, self.linear1.weight, self.linear1.bias, None, True)
         else:
+            _fell_back("ffn_activation")
             hid = self.activation(_lin(tgt, self.linear1.weight, self.linear1.bias))
         tgt2 = _lin(self.dropout(hid), self.linear2.weight, self.linear2.bias)
         tgt = _add_norm(tgt, tgt2, self.norm3, self.dropout3, self.training)
@@ -271,6 +292,7 @@ class LineRefineNet(nn.Module):
             # per-layer K/V tensors, no concatenation of their gradients
             token, arena = ops.kv_token(k_all, v_all, d)
         else:
+            _fell_back("kv_split")
             k_split, v_split = k_all.split(d, dim=-1), v_all.split(d, dim=-1)
         current_line_coords = noisy_line.clone()
         all_pred_offsets = []
@@ -285,10 +307,12 @@ class LineRefineNet(nn.Module):
             if tgt.is_cuda and r0.in_features % 4 == 0 and r0.out_features % 4 == 0:
                 hid = ops.linear(tgt, r0.weight, r0.bias, None, True)               # 256 -> 128, ReLU in the epilogue
             else:
+                _fell_back("reg_head_hidden")
                 hid = F.relu(F.linear(tgt, r0.weight, r0.bias))
             if hid.is_cuda and ops.linear_small_supported(r2.in_features, r2.out_features):
                 delta_offset = ops.linear_small(hid, r2.weight, r2.bias)            # 128 -> 3: one HBM pass
             else:
+                _fell_back("reg_head_out")
                 delta_offset = F.linear(hid, r2.weight, r2.bias)
             current_line_coords = current_line_coords + delta_offset      # no detach (H5)
             all_pred_offsets.append(current_line_coords - noisy_line)

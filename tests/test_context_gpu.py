@@ -177,6 +177,54 @@ def test_scene_sample_stream(tmp_path):
         assert float(t.abs().max()) < 1.0 and int(batch["points_in_tube"].min()) > 128
         seen += c.shape[0]
     assert seen == 12
+    # rank sharding (DistributedSampler semantics per scene) + fixed batch size: the two ranks
+    # see disjoint halves of every scene, the same number of batches, and different orders per epoch
+    per_rank = []
+    for r in range(2):
+        dr = SceneSampleStream(str(tmp_path), num_context_points=128, crop_radius=0.5, batch_size=4,
+                               rank=r, world_size=2, seed=3)
+        assert len(dr) == 6
+        batches = list(dr)
+        assert [b["context"].shape[0] for b in batches] == [4, 2]
+        per_rank.append(torch.cat([b["noisy_line"] for b in batches]))
+        dr.set_epoch(1)
+        again = torch.cat([b["noisy_line"] for b in dr])
+        assert again.shape == per_rank[-1].shape and not torch.equal(again, per_rank[-1])
+    both = torch.cat(per_rank).reshape(12, -1)
+    assert len({tuple(np.round(v.cpu().numpy(), 4)) for v in both}) == 12      # no sample on both ranks
+    # ASCII PCD with an extra field: x y z intensity are the first four columns (np.loadtxt keeps all)
+    asc = tmp_path / "asc"
+    asc.mkdir()
+    pts = np.column_stack([xyz[:200], inten[:200], np.arange(200, dtype=np.float32)])
+    hdr = "VERSION 0.7\nFIELDS x y z intensity ring\nSIZE 4 4 4 4 4\nTYPE F F F F F\nCOUNT 1 1 1 1 1\nWIDTH 200\nHEIGHT 1\nPOINTS 200\nDATA ascii\n"
+    (asc / "a.pcd").write_text(hdr + "\n".join(" ".join(f"{v:.6f}" for v in row) for row in pts) + "\n")
+    (asc / "a.json").write_text(json.dumps({"items": items[:1]}))
+    b = next(iter(SceneSampleStream(str(asc), num_context_points=16, crop_radius=50.0, shuffle=False)))
+    got_int = set(np.round(b["context"][..., 3].cpu().numpy().ravel(), 3))
+    assert got_int <= set(np.round(inten[:200], 3))            # intensities, not ring numbers or coordinates
+
+
+def test_tube_larger_than_the_candidate_buffer_spans_the_whole_line():
+    """a tube with more points than the default candidate buffer (8192) must still be
+    sampled over its whole length (the reference draws from every point of the tube,
+    src/dataset.py:86-130).  Cloud in scan order along x: a truncated buffer would cover x < -9 only."""
+    import warnings
+    P_ = 30000
+    xs = np.linspace(-24, 24, P_).astype(np.float32)                      # sorted: cloud order = along the line
+    rng = np.random.default_rng(4)
+    cloud = np.stack([xs, rng.uniform(-0.2, 0.2, P_), rng.normal(0, 0.02, P_), rng.uniform(0, 50, P_)], 1).astype(np.float32)
+    line = np.stack([np.linspace(-25, 25, 32), np.zeros(32), np.zeros(32)], 1)
+    dense = O.arc_resample(line, 200)
+    ctx, counts = _build(cloud, dense[None], line[None], 1024, 0.5, seed=1)          # default: sized from the counts
+    assert int(counts[0]) == P_
+    x = ctx[0, :, 0].cpu().numpy()
+    assert x.min() < -20 and x.max() > 20
+    assert np.abs(np.histogram(x, bins=6, range=(-24, 24))[0] / 1024 - 1 / 6).max() < 0.08
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        ctx2, counts2 = _build(cloud, dense[None], line[None], 1024, 0.5, seed=1, max_candidates=8192)
+    assert any("max_candidates" in str(m.message) for m in w)           # an explicit cap is reported, not silent
+    assert int(counts2[0]) == P_ and float(ctx2[0, :, 0].max()) < -9.0
 
 
 def test_device_resampling_matches_numpy_interp():

@@ -161,3 +161,41 @@ def test_split16_operand_scales():
         assert float((c - ref)[rows].abs().max()) < 1e-6 * 1e6 * 2 ** -9   # to outlier * 2^-22-ish floor
     finally:
         lib.prh_set_gemm_mode(old)
+
+
+def test_split16_component_wise_rows_far_below_the_maximum():
+    """The per-tensor power-of-two scale of the split-fp16 core, component-wise (VERDICT r01
+    weak 3): a dgrad-shaped operand whose rows sit 2^-g below the tensor's largest entry.  Rows
+    within 2^-16 of the maximum keep all 22 split bits (per-row rel-L2 at fp32 level); below
+    that the low plane runs into fp16's denormal spacing and a row loses about one bit per
+    factor of two - an ABSOLUTE floor of 2^-25 of the tensor maximum per element, never garbage:
+    2^-20 -> < 2e-5 per row, 2^-24 -> < 4e-4.  The three-plane bf16 mode has no such dependence."""
+    from pointnet_refine_amd import _lib
+    lib = _lib.lib()
+    m, n, k = 2048, 1984, 1024           # fusion-dgrad shape: K = 1024 output channels, N = 1984
+    g = torch.Generator(device="cuda").manual_seed(13)
+    a = torch.randn(m, k, device="cuda", generator=g)
+    gaps = {0: 0, 1: 12, 2: 16, 3: 20, 4: 24}
+    for r, gp in gaps.items():
+        a[r::8] *= 2.0 ** -gp            # rows 5..7 of every 8 stay at scale 1 (they hold the maximum)
+    w = torch.randn(n, k, device="cuda", generator=g)
+    ref = a.double() @ w.double().t()
+    nb = lib.prh_linear_forward_workspace_bytes(m, k, n)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    old = lib.prh_get_gemm_mode()
+    try:
+        errs = {}
+        for mode in (3, 1):
+            lib.prh_set_gemm_mode(mode)
+            c = torch.empty(m, n, device="cuda")
+            assert lib.prh_test_gemm_nt(_p(a), _p(w), _p(c), m, n, k, _p(ws), nb, 0, st) == 0
+            d = (c.double() - ref)
+            errs[mode] = {gp: float((d[r::8].norm(dim=1) / ref[r::8].norm(dim=1)).max()) for r, gp in gaps.items()}
+    finally:
+        lib.prh_set_gemm_mode(old)
+    e3, e1 = errs[3], errs[1]
+    assert e3[0] < 1e-6 and e3[12] < 1e-6 and e3[16] < 2e-6, e3
+    assert e3[20] < 2e-5 and e3[24] < 4e-4, e3
+    assert e3[24] > e3[12]                                # the degradation is real, and bounded
+    assert max(e1.values()) < 1e-6, e1                    # split-bf16 (3 planes): no range dependence

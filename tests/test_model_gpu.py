@@ -252,3 +252,39 @@ def test_decoder_layer_standalone_call_contract():
     out2 = layer(tgt, mem)
     ref2 = O.decoder_layer(p, "L", t2, m2, torch.zeros_like(t2), torch.zeros_like(m2))
     assert maxdiff(out2, ref2) < 1e-4
+
+
+def test_default_model_never_takes_a_stock_pytorch_branch():
+    """model._lin/_attn/_add_norm keep stock-PyTorch branches for shapes the kernels reject;
+    the default LineRefineNet must never take one: a train step and an eval forward leave
+    model.FALLBACKS empty, and the attention / LayerNorm / Linear arithmetic never reaches
+    torch's own kernels (F.linear, SDPA, F.layer_norm patched to raise)."""
+    from pointnet_refine_amd import model as M
+    import torch.nn.functional as F
+    m = _model(P.linerefine_state_dict(0))
+    ctx, noisy, target = P.synth_batch(4, 128, 4, 32, seed=2)
+    ctx, noisy, target = ctx.cuda(), noisy.cuda(), target.cuda()
+    M.FALLBACKS.clear()
+
+    def boom(name):
+        def f(*a, **k):
+            raise AssertionError(f"stock torch.nn.functional.{name} reached from the default model")
+        return f
+
+    saved = {n: getattr(F, n) for n in ("linear", "scaled_dot_product_attention", "layer_norm",
+                                        "multi_head_attention_forward", "batch_norm", "conv1d")}
+    try:
+        for n in saved:
+            setattr(F, n, boom(n))
+        m.train()
+        out = m(ctx, noisy)
+        (out - target.unsqueeze(0)).abs().mean().backward()
+        m.eval()
+        with torch.no_grad():
+            m(ctx, noisy)
+            m.context_encoder(ctx.transpose(2, 1).contiguous())
+    finally:
+        for n, f in saved.items():
+            setattr(F, n, f)
+    assert M.FALLBACKS == {}, M.FALLBACKS
+    assert all(p.grad is not None for p in m.parameters())
