@@ -80,7 +80,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the exact-fp32 parity step after the timed region")
     ap.add_argument("--kernels", type=int, default=0, help="print the K longest GEMM launches (live HIP-event times) to stderr")
-    ap.add_argument("--cpu-batch", type=int, default=64)
+    ap.add_argument("--cpu-batch", type=int, default=16,
+                    help="segments in the CPU sample (16: the host's best throughput; 64 measured 2.5x slower per segment)")
     ap.add_argument("--stub", action="store_true",
                     help="launcher self-test: a small CPU stand-in model over the gloo backend instead of "
                          "the HIP model over RCCL (tests/test_bench_launcher_cpu.py); not a measurement")
@@ -134,7 +135,7 @@ def step_flops(batch, points, line_points=32):
 def cpu_baseline(points, batch):
     """Oracle (port of the reference) on the host cores, bounded sample: the three figures of
     BASELINE.md section 4 - (a) full forward+backward, (b) encoder-only forward+backward,
-    (c) eval forward - 1 warm-up + best of 2 each."""
+    (c) eval forward - 1 warm-up + best of 3 each."""
     import torch
     from oracle import linerefine_oracle as O
     from oracle import procedural as P
@@ -161,7 +162,7 @@ def cpu_baseline(points, batch):
     res = {}
     for name, fn in (("full_fwd_bwd", full), ("encoder_fwd_bwd", encoder), ("eval_forward", evalf)):
         best = float("inf")
-        for it in range(3):
+        for it in range(4):
             t0 = time.perf_counter()
             fn()
             dt = time.perf_counter() - t0
@@ -172,7 +173,7 @@ def cpu_baseline(points, batch):
     return {"value": res["full_fwd_bwd"], "unit": "segments/s", "cores": nt, "kind": "port",
             "encoder_fwd_bwd": res["encoder_fwd_bwd"], "eval_forward": res["eval_forward"],
             "sample": f"oracle/linerefine_oracle.py, B={batch}, N={points}, fp32, torch-CPU {nt} threads, "
-                      f"1 warm-up + best of 2 each: value = full forward+backward (no optimizer); "
+                      f"1 warm-up + best of 3 each: value = full forward+backward (no optimizer); "
                       f"encoder_fwd_bwd = MultiScalePointNetEncoder alone; eval_forward = no_grad forward"}
 
 
