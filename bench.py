@@ -264,6 +264,7 @@ def parity_check(step, model, batch, lib, mode, dev):
                 v.copy_(snap[k])
     (oa, ga, la), (ob, gb, lb) = res["bench"], res["exact"]
     out_err = float((oa - ob).abs().max())
+    out_rel = float((oa.double() - ob.double()).norm() / (ob.double().norm() + 1e-30))
     worst, worst_name, off = 0.0, "", 0
     gmax = 0.0
     per = []
@@ -279,7 +280,7 @@ def parity_check(step, model, batch, lib, mode, dev):
             if r > worst:
                 worst, worst_name = r, n
     total = float((ga.double() - gb.double()).norm() / (gb.double().norm() + 1e-30))
-    return {"out_max_abs_vs_exact_fp32": out_err, "worst_grad_rel_l2": worst, "worst_grad": worst_name,
+    return {"out_max_abs_vs_exact_fp32": out_err, "out_rel_l2_vs_exact_fp32": out_rel, "worst_grad_rel_l2": worst, "worst_grad": worst_name,
             "all_grads_rel_l2": total, "loss": la, "loss_exact_fp32": lb}
 
 
@@ -443,12 +444,18 @@ def run(args):
     if lib is not None and not args.no_parity and not args.graph:
         try:
             parity = parity_check(step, model, (ctx, noisy, target), lib, mode, dev)
-            exact = mode in (0, 1, 3)
-            gate = {"out": 1e-4 if exact else 5e-2, "grad_rel_l2": 2e-3 if exact else None}
+            if mode in (0, 1, 3):      # fp32-accurate cores: the north_star's 1e-4 on the outputs
+                gate = {"out_max_abs": 1e-4, "worst_grad_rel_l2": 2e-3}
+                parity["ok"] = bool(parity["out_max_abs_vs_exact_fp32"] <= 1e-4 and parity["worst_grad_rel_l2"] <= 2e-3)
+            else:
+                # reduced precision: SURVEY 8(d)'s 5e-2, read as a relative figure (it was taken from
+                # the reference under bf16 autocast: 1.7e-2 rel-L2 = 7.9e-2 max-abs in eval mode, and
+                # 5.9e-2 / 4.0e-1 in train mode on the G2 inputs - tests/golden/g9_bf16_autocast.npz)
+                gate = {"out_rel_l2": 5e-2, "reference_under_bf16_autocast": {"train_out_rel_l2": 5.9e-2,
+                                                                              "train_out_max_abs": 0.397}}
+                parity["ok"] = bool(parity["out_rel_l2_vs_exact_fp32"] <= 5e-2)
             parity["gate"] = gate
-            parity["ok"] = bool(parity["out_max_abs_vs_exact_fp32"] <= gate["out"] and
-                                (gate["grad_rel_l2"] is None or parity["worst_grad_rel_l2"] <= gate["grad_rel_l2"]))
-            for k in ("out_max_abs_vs_exact_fp32", "worst_grad_rel_l2", "all_grads_rel_l2"):
+            for k in ("out_max_abs_vs_exact_fp32", "out_rel_l2_vs_exact_fp32", "worst_grad_rel_l2", "all_grads_rel_l2"):
                 parity[k] = float(f"{parity[k]:.4g}")
             if rank == 0:
                 log(f"parity at B={B}, N={N}: {parity}")

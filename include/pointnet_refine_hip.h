@@ -116,6 +116,43 @@ int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B,
                          float* d_ctx, void* workspace, size_t workspace_bytes, int device,
                          void* stream);
 
+/* ---- bf16 mode (BASELINE config 3, "bf16 training"; prh_set_gemm_mode(4)) -----------------
+ * Same encoder (src/model.py:39-62) with ONE bf16 MFMA product per MAC and the activations the
+ * forward keeps - and `fused`, and the gradient buffers of the backward - STORED in bf16
+ * (uint16_t = raw bf16 bits).  Accumulation, BatchNorm statistics (taken from the rounded
+ * values), parameters and parameter gradients are fp32.  Channel widths must be multiples of 8
+ * (the context rows are padded to 8 channels internally). */
+typedef struct {
+  uint16_t* z_cat;   /* [P, cat]      bf16 pre-BN outputs of conv1..5 */
+  uint16_t* z_fus;   /* [P, out_dim]  bf16 pre-BN output of the fusion conv */
+  uint16_t* gate;    /* [P, out_dim]  bf16 0.5+0.5*sigmoid(.) ; may be NULL when no backward */
+  float* bn_scale;   /* [cat+out_dim] as in prh_encoder_saved */
+  float* bn_shift;
+  float* bn_mean;
+  float* bn_rstd;
+  int32_t* argmax;   /* [B, out_dim] or NULL */
+} prh_encoder_saved_bf16;
+size_t prh_encoder_bf16_workspace_bytes(int B, int N, int in_channel, int out_dim, int backward);
+/* fused [B,N,out_dim] bf16; everything else as prh_encoder_forward */
+int prh_encoder_forward_bf16(const prh_encoder_params* prm, const float* ctx, int B, int N, int training,
+                             float momentum, float eps, uint16_t* fused, float* gfeat,
+                             const prh_encoder_saved_bf16* saved, void* workspace, size_t workspace_bytes,
+                             int device, void* stream);
+/* d_fused [B,N,out_dim] bf16 or NULL; everything else as prh_encoder_backward */
+int prh_encoder_backward_bf16(const prh_encoder_params* prm, const float* ctx, int B, int N, int training,
+                              const uint16_t* d_fused, const float* d_gfeat, const prh_encoder_saved_bf16* saved,
+                              const prh_encoder_grads* grads, float* d_ctx, void* workspace,
+                              size_t workspace_bytes, int device, void* stream);
+/* nn.Linear on a bf16 input (context_proj applied to the bf16 `fused`, src/model.py:147,194):
+ * y fp32 [rows,n] = act(x W^T + b); backward: dy fp32 -> dx bf16 [rows,k], dw [n,k], db [n]
+ * (any may be NULL).  k, n, ldx multiples of 8. */
+size_t prh_linear_bf16_workspace_bytes(int rows, int k, int n, int backward);
+int prh_linear_forward_bf16(const uint16_t* x, long ldx, const float* w, const float* b, float* y, int rows, int k,
+                            int n, int relu, void* workspace, size_t workspace_bytes, int device, void* stream);
+int prh_linear_backward_bf16(const uint16_t* x, long ldx, const float* w, const float* dy, uint16_t* dx, float* dw,
+                             float* db, int rows, int k, int n, void* workspace, size_t workspace_bytes, int device,
+                             void* stream);
+
 /* nn.Linear forward y = act(x W^T + b): context_proj (src/model.py:147,194) and any
  * other Linear on the path.  x [rows,k] (ld ldx), w [n,k], y [rows,n]; relu: 0/1.
  * k and ldx must be multiples of 4.  workspace (may be NULL: exact fp32 MFMA core only) holds the
@@ -298,8 +335,12 @@ int prh_attn_backward_ex(const float* q, long ldq, const float* k, long ldk, con
  *            fp32-level error with no range assumption;
  *   fp32 / 0: the exact fp32 MFMA cores (v_mfma_f32_32x32x2_f32) everywhere.
  * All three are checked against the oracle at the same 1e-4 gate.
- *   bf16 / 2: opt-in REDUCED-PRECISION mode (BASELINE config 3): plain bf16 operands, one MFMA
- *            product, fp32 accumulate and fp32 storage; its parity gate is 5e-2, not 1e-4.
+ *   bf16 / 2: opt-in REDUCED-PRECISION mode: plain bf16 operands, one MFMA product on the
+ *            first-generation cores, fp32 accumulate and fp32 storage; parity gate 5e-2, not 1e-4.
+ *   bf16s / 4: BASELINE config 3 ("bf16 training"): bf16 operands AND bf16 activation storage.
+ *            The encoder and the Linear fed by it go through the *_bf16 entry points above; plain
+ *            fp32-storage Linears of at least 512 x 64 x 64 run on the same bf16 core with their
+ *            input converted in flight; everything else behaves as mode 2.  Parity gate 5e-2.
  * The mode is process-wide; set it before launching work, not concurrently with it, and keep
  * it unchanged between a forward call and its backward. */
 int prh_set_gemm_mode(int mode);

@@ -51,8 +51,16 @@ class EncoderSaved(C.Structure):
                 ("bn_rstd", C.c_void_p), ("argmax", C.c_void_p), ("op_amax", C.c_void_p)]
 
 
+class EncoderSavedBf16(C.Structure):
+    _fields_ = [("z_cat", C.c_void_p), ("z_fus", C.c_void_p), ("gate", C.c_void_p),
+                ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p), ("bn_mean", C.c_void_p),
+                ("bn_rstd", C.c_void_p), ("argmax", C.c_void_p)]
+
+
 EXPORTS = [
     "prh_encoder_workspace_bytes", "prh_encoder_forward", "prh_encoder_backward",
+    "prh_encoder_bf16_workspace_bytes", "prh_encoder_forward_bf16", "prh_encoder_backward_bf16",
+    "prh_linear_bf16_workspace_bytes", "prh_linear_forward_bf16", "prh_linear_backward_bf16",
     "prh_linear_forward_workspace_bytes", "prh_linear_forward", "prh_linear_forward_ex",
     "prh_linear_forward_full", "prh_operand_absmax_workspace_bytes", "prh_operand_absmax",
     "prh_linear_uses_operand_maxima", "prh_linear_backward_full", "prh_pos_hidden_forward", "prh_pos_hidden_backward_workspace_bytes",
@@ -108,6 +116,21 @@ def _bind(lib):
     lib.prh_encoder_backward.argtypes = [C.POINTER(EncoderParams), vp, i, i, i, vp, vp,
                                          C.POINTER(EncoderSaved), C.POINTER(EncoderGrads), vp, vp,
                                          sz, i, vp]
+    lib.prh_encoder_bf16_workspace_bytes.restype = sz
+    lib.prh_encoder_bf16_workspace_bytes.argtypes = [i, i, i, i, i]
+    lib.prh_encoder_forward_bf16.restype = i
+    lib.prh_encoder_forward_bf16.argtypes = [C.POINTER(EncoderParams), vp, i, i, i, f, f, vp, vp,
+                                             C.POINTER(EncoderSavedBf16), vp, sz, i, vp]
+    lib.prh_encoder_backward_bf16.restype = i
+    lib.prh_encoder_backward_bf16.argtypes = [C.POINTER(EncoderParams), vp, i, i, i, vp, vp,
+                                              C.POINTER(EncoderSavedBf16), C.POINTER(EncoderGrads), vp, vp,
+                                              sz, i, vp]
+    lib.prh_linear_bf16_workspace_bytes.restype = sz
+    lib.prh_linear_bf16_workspace_bytes.argtypes = [i, i, i, i]
+    lib.prh_linear_forward_bf16.restype = i
+    lib.prh_linear_forward_bf16.argtypes = [vp, lg, vp, vp, vp, i, i, i, i, vp, sz, i, vp]
+    lib.prh_linear_backward_bf16.restype = i
+    lib.prh_linear_backward_bf16.argtypes = [vp, lg, vp, vp, vp, vp, vp, i, i, i, vp, sz, i, vp]
     lib.prh_linear_forward.restype = i
     lib.prh_linear_forward.argtypes = [vp, lg, vp, vp, vp, i, i, i, i, vp, sz, i, vp]
     lib.prh_linear_forward_ex.restype = i

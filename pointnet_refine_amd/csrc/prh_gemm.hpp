@@ -267,13 +267,13 @@ __device__ __forceinline__ void epi_block_to_scratch(const f32x4 (&acc)[MB][4], 
 }
 template <int MT>
 __device__ __forceinline__ void epi_col_stats(const f32x16 (&acc)[MT][2], const NTParams& p, int cbase,
-                                              int mrows, int rb, int lane) {
+                                              int mrows, int rb, int lane, const float* biasp) {
   const int half = lane >> 5, l31 = lane & 31;
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     const int col = cbase + nt * 32 + l31;
     const bool cok = col < p.N;
-    const float bias = (p.bias != nullptr && cok) ? p.bias[col] : 0.f;
+    const float bias = (biasp != nullptr && cok) ? biasp[col] : 0.f;
     float s = 0.f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -316,13 +316,13 @@ __device__ __forceinline__ void epi_col_stats(const f32x16 (&acc)[MT][2], const 
 }
 template <int MB>
 __device__ __forceinline__ void epi_col_stats(const f32x4 (&acc)[MB][4], const NTParams& p, int cbase,
-                                              int mrows, int rb, int lane) {
+                                              int mrows, int rb, int lane, const float* biasp) {
   const int q = lane >> 4, l15 = lane & 15;
 #pragma unroll
   for (int nb = 0; nb < 4; ++nb) {
     const int col = cbase + nb * 16 + l15;
     const bool cok = col < p.N;
-    const float bias = (p.bias != nullptr && cok) ? p.bias[col] : 0.f;
+    const float bias = (biasp != nullptr && cok) ? biasp[col] : 0.f;
     float s = 0.f;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
@@ -368,13 +368,45 @@ __device__ __forceinline__ void epi_col_stats(const f32x4 (&acc)[MB][4], const N
   }
 }
 
-template <int EPI, int MT, class ACC>
+// 16-bit storage helpers of the bf16-storage mode (prh_b16.hpp): element offsets, H = the
+// buffer holds bf16 (2 bytes per element) instead of fp32
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  typedef __bf16 v2b __attribute__((ext_vector_type(2)));
+  v2f v = {a, b};
+  v2b h = __builtin_convertvector(v, v2b);        // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
+  return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ float bf16_round(float x) { return bf16_lo(pack_bf16x2(x, 0.f)); }
+template <bool H>
+__device__ __forceinline__ float4 ld4e(const char* base, int off) {
+  if (H) {
+    const uint2 u = *reinterpret_cast<const uint2*>(base + (size_t)off * 2);
+    return make_float4(bf16_lo(u.x), bf16_hi(u.x), bf16_lo(u.y), bf16_hi(u.y));
+  }
+  return *reinterpret_cast<const float4*>(base + (size_t)off * 4);
+}
+template <bool H>
+__device__ __forceinline__ void st4e(char* base, int off, float4 v) {
+  if (H) *reinterpret_cast<uint2*>(base + (size_t)off * 2) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+  else *reinterpret_cast<float4*>(base + (size_t)off * 4) = v;
+}
+
+// C16: C, C2, the accumulated-into C and the matrix-shaped E1 are bf16 buffers (leading
+// dimensions in elements); a row-vector E1 (F_E1_ROWVEC: one fp32 value per row) stays fp32.
+template <int EPI, int MT, class ACC, bool C16 = false>
 __device__ __forceinline__ void nt_epilogue_vec(ACC& acc, const NTParams& p, int rbase_,
-                                                int cbase, int rb, int lane, float* scratch) {
-  const int half = lane >> 5, l31 = lane & 31;
+                                                int cbase, int rb, int lane, float* scratch,
+                                                bool bias_done = false) {     // bias already in acc
   const int rbase = __builtin_amdgcn_readfirstlane(rbase_);
-  float* __restrict__ Cb = p.C + (size_t)rbase * p.ldc;
-  const float* __restrict__ Eb = p.E1 != nullptr ? p.E1 + (size_t)rbase * p.lde1 : nullptr;
+  const float* biasp = bias_done ? nullptr : p.bias;
+  constexpr int ES = C16 ? 2 : 4;
+  const bool rowvec = EPI == EPI_DGRAD && (p.flags & F_E1_ROWVEC) != 0;
+  const int ees = (C16 && !rowvec) ? 2 : 4;
+  char* __restrict__ Cb = reinterpret_cast<char*>(p.C) + (size_t)rbase * p.ldc * ES;
+  const char* __restrict__ Eb = p.E1 != nullptr ? reinterpret_cast<const char*>(p.E1) + (size_t)rbase * p.lde1 * ees : nullptr;
   const int ldc = (int)p.ldc, lde1 = (int)p.lde1;
   const int mrows = p.M - rbase;
   const int rr = lane >> 4, c4 = (lane & 15) * 4;     // row-major phase: 4 rows x 16 float4
@@ -382,17 +414,17 @@ __device__ __forceinline__ void nt_epilogue_vec(ACC& acc, const NTParams& p, int
   const bool c4ok = col4 < p.N;
   float4 bias4 = zero4(), es4 = zero4(), et4 = zero4();
   if (c4ok) {
-    if (p.bias != nullptr) bias4 = ldg4(p.bias + col4);
+    if (biasp != nullptr) bias4 = ldg4(biasp + col4);
     if ((EPI == EPI_DGRAD && (p.flags & F_MASK) != 0) || EPI == EPI_GATE) {
       es4 = ldg4(p.es + col4);
       et4 = ldg4(p.et + col4);
     }
   }
-  float* __restrict__ C2b = (EPI == EPI_GATE && p.C2 != nullptr) ? p.C2 + (size_t)rbase * p.ldc2 : nullptr;
+  char* __restrict__ C2b = (EPI == EPI_GATE && p.C2 != nullptr) ? reinterpret_cast<char*>(p.C2) + (size_t)rbase * p.ldc2 * ES : nullptr;
   const int ldc2 = (int)p.ldc2;
 
   // statistics straight from the accumulators (column on the lane): sum, then centred M2
-  if (EPI == EPI_BIAS_STATS) epi_col_stats(acc, p, cbase, mrows, rb, lane);
+  if (EPI == EPI_BIAS_STATS) epi_col_stats(acc, p, cbase, mrows, rb, lane, biasp);
 
   const bool mask = (p.flags & F_MASK) != 0, accum = (p.flags & F_ACCUM) != 0;
   const bool resid = EPI == EPI_BIAS && (p.flags & F_RESID) != 0;
@@ -406,8 +438,8 @@ __device__ __forceinline__ void nt_epilogue_vec(ACC& acc, const NTParams& p, int
   // row groups: ~100 serialized round trips per tile.
   const int col4c = col4 < p.N ? col4 : (p.N - 4);
   // load bases: a wave tile entirely below the matrix reads (and discards) row 0 instead
-  const float* __restrict__ Cl = mrows > 0 ? Cb : p.C;
-  const float* __restrict__ El = mrows > 0 ? Eb : p.E1;
+  const char* __restrict__ Cl = mrows > 0 ? Cb : reinterpret_cast<const char*>(p.C);
+  const char* __restrict__ El = mrows > 0 ? Eb : reinterpret_cast<const char*>(p.E1);
   const bool acc_old = EPI == EPI_DGRAD && accum;
   // Batches of 4 row groups (two per 32-row block), software-pipelined one deep: batch b+1's
   // operand loads are issued before batch b is processed.  (Measured against the unpipelined
@@ -418,7 +450,7 @@ __device__ __forceinline__ void nt_epilogue_vec(ACC& acc, const NTParams& p, int
   auto issue = [&](int b, float4 (&z)[4], float4 (&o)[4]) {
     // pin each batch's loads to its place (the operand pointers are read-only/restrict, so the
     // bases are laundered through an asm statement; loads hoisted further up spill accumulators)
-    const float* Em = El; const float* Cm = Cl;
+    const char* Em = El; const char* Cm = Cl;
     asm volatile("" : "+s"(Em), "+s"(Cm) : : "memory");
     int lrc[4];
 #pragma unroll
@@ -429,12 +461,20 @@ __device__ __forceinline__ void nt_epilogue_vec(ACC& acc, const NTParams& p, int
       lrc[i] = r < 0 ? 0 : r;
     }
     if (need_z) {        // wave-uniform: one batch of loads
+      if (rowvec) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) z[i] = ldg4(Em + lrc[i] * lde1 + col4c);
+        for (int i = 0; i < 4; ++i) {
+          const float s = *reinterpret_cast<const float*>(Em + (size_t)(lrc[i] * lde1) * 4);
+          z[i] = make_float4(s, s, s, s);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z[i] = ld4e<C16>(Em, lrc[i] * lde1 + col4c);
+      }
     }
     if (acc_old) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = ldg4(Cm + lrc[i] * ldc + col4c);
+      for (int i = 0; i < 4; ++i) o[i] = ld4e<C16>(Cm, lrc[i] * ldc + col4c);
     }
   };
   issue(0, zz[0], oo[0]);
@@ -463,6 +503,9 @@ __device__ __forceinline__ void nt_epilogue_vec(ACC& acc, const NTParams& p, int
           v.z = fmaf(z.z, es4.z, et4.z) > 0.f ? v.z : 0.f;
           v.w = fmaf(z.w, es4.w, et4.w) > 0.f ? v.w : 0.f;
         }
+        if (C16) {      // the statistics describe the values the consumers will read back
+          v.x = bf16_round(v.x); v.y = bf16_round(v.y); v.z = bf16_round(v.z); v.w = bf16_round(v.w);
+        }
         const float4 q = ok ? v : zero4();
         s1.x += q.x; s1.y += q.y; s1.z += q.z; s1.w += q.w;
         s2.x = fmaf(q.x, z.x, s2.x); s2.y = fmaf(q.y, z.y, s2.y);
@@ -474,14 +517,14 @@ __device__ __forceinline__ void nt_epilogue_vec(ACC& acc, const NTParams& p, int
         m.z = 0.5f + 0.5f / (1.f + __expf(-v.z)); m.w = 0.5f + 0.5f / (1.f + __expf(-v.w));
         v.x = fmaxf(fmaf(z.x, es4.x, et4.x), 0.f) * m.x; v.y = fmaxf(fmaf(z.y, es4.y, et4.y), 0.f) * m.y;
         v.z = fmaxf(fmaf(z.z, es4.z, et4.z), 0.f) * m.z; v.w = fmaxf(fmaf(z.w, es4.w, et4.w), 0.f) * m.w;
-        if (ok && (p.flags & F_STORE_GATE) != 0) *reinterpret_cast<float4*>(C2b + lr * ldc2 + col4) = m;
+        if (ok && (p.flags & F_STORE_GATE) != 0) st4e<C16>(C2b, lr * ldc2 + col4, m);
       } else {
         if (resid) { v.x += z.x; v.y += z.y; v.z += z.z; v.w += z.w; }
         if ((p.flags & F_RELU_OUT) != 0) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
       }
-      if (ok) *reinterpret_cast<float4*>(Cb + lr * ldc + col4) = v;
+      if (ok) st4e<C16>(Cb, lr * ldc + col4, v);
     }
     // keep the running column sums here: left alone, the compiler sinks all 64 accumulation
     // steps into the F_STATS branch below and carries every v and z there (32 spilled VGPRs,

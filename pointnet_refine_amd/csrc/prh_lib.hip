@@ -18,6 +18,7 @@
 #include "prh_attn.hpp"
 #include "prh_gemm_s3.hpp"
 #include "prh_gemm_h2.hpp"
+#include "prh_b16.hpp"
 #include "prh_context.hpp"
 #include "prh_kernels.hpp"
 
@@ -116,16 +117,21 @@ inline int gemm_mode() {
     else if (e != nullptr && strcmp(e, "split") == 0) g_gemm_mode = 1;
     else if (e != nullptr && strcmp(e, "bf16") == 0) g_gemm_mode = 2;
     else if (e != nullptr && strcmp(e, "split16") == 0) g_gemm_mode = 3;
+    else if (e != nullptr && strcmp(e, "bf16s") == 0) g_gemm_mode = 4;
   }
   return g_gemm_mode;
 }
+// Mode 4 (bf16 operands AND bf16 activation storage, prh_b16.hpp) has its own encoder / Linear
+// entry points; whatever still goes through the generic fp32-storage launchers in that mode
+// (point_mlp stack, odd shapes) is served like mode 2: one bf16 plane on the first-generation cores.
+inline int core_mode() { return gemm_mode() == 4 ? 2 : gemm_mode(); }
 // PRH_H2_GEN=1 keeps the split-fp16 NT GEMMs on the first-generation core (32x32x16 MFMA, BK 16)
 bool g_h2_gen2 = [] { const char* e = getenv("PRH_H2_GEN"); return !(e && strcmp(e, "1") == 0); }();
 // PRH_TN_TR=0 keeps the split-fp16 wgrads on the column-staged core
 int g_tn_skew = [] { const char* e = getenv("PRH_TN_SKEW"); return e ? atoi(e) : 0; }();   // diagnostic
 bool g_tn_pace = [] { const char* e = getenv("PRH_TN_PACE"); return !(e && strcmp(e, "0") == 0); }();
 bool g_tn_tr = [] { const char* e = getenv("PRH_TN_TR"); return !(e && strcmp(e, "0") == 0); }();
-inline const char* core_tag() { return gemm_mode() == 2 ? "b1" : (gemm_mode() == 3 ? "h2" : "s3"); }
+inline const char* core_tag() { return core_mode() == 2 ? "b1" : (core_mode() == 3 ? "h2" : "s3"); }
 
 // largest |pro(A)| over [rows, cols] into *slot; part: ABSMAX_MAX_BLOCKS floats of scratch
 template <int PRO>
@@ -191,6 +197,125 @@ inline size_t nt_s3_lds(int K, int pro) {
 }
 static_assert(8 * 32 * EPI_LDW * 4 <= S3_LDS, "epilogue scratch must fit in the stage buffers");
 
+// ------------------------------------------------------------------ bf16 mode launchers (prh_b16.hpp)
+// C[M,N] = pro(A) W^T on the bf16 NT core.  A bf16 (A16) or fp32, C / C2 / matrix E1 bf16 (C16)
+// or fp32.  p.wprep must hold b16_weight_bytes(N, K).  Leading dimensions in elements.
+template <int PRO, int EPI, bool A16, bool C16>
+int launch_nt_b16(NTParams& p, hipStream_t st, StatInfo* si = nullptr) {
+  if (p.M <= 0 || p.N <= 0) return PRH_OK;
+  const bool rowvec = (p.flags & F_E1_ROWVEC) != 0;
+  if ((p.K & 7) || (PRO != PRO_GATE1 && (p.lda & (A16 ? 7 : 3))) || (p.ldw & 3) || (p.N & 3) || (p.ldc & 3) ||
+      (p.E1 != nullptr && !rowvec && (p.lde1 & 3)) || (p.C2 != nullptr && (p.ldc2 & 3)) || p.wprep == nullptr)
+    return fail(PRH_ERR_ARG, "gemm_nt_b16: K %% 8, N %% 4 and aligned leading dimensions required (K=%d N=%d lda=%ld ldc=%ld)",
+                p.K, p.N, p.lda, p.ldc);
+  const int KT = cdiv(p.K, B16_BK), NTl = cdiv(p.N, 256);
+  const size_t lds = (size_t)H2_LDS + (PRO == PRO_NONE ? 0 : 2 * (size_t)(KT + 2) * B16_BK * 4);
+  if (lds > 160 * 1024) return fail(PRH_ERR_ARG, "gemm_nt_b16: K=%d too deep for the prologue coefficient image", p.K);
+  const long th = (long)NTl * 256 * KT * 8;
+  hipLaunchKernelGGL(prep_weights_b16_kernel, dim3((unsigned)cdiv(th, 256)), dim3(256), 0, st, p.W, p.N, p.K, p.ldw,
+                     p.wprep + S3_WHDR);
+  LAUNCH_CHECK();
+  p.tiles_n = NTl;
+  static const int attr = allow_big_lds(gemm_nt_b16_kernel<PRO, EPI, A16, C16>);
+  if (attr != PRH_OK) return attr;
+  char nm[64];
+  snprintf(nm, sizeof(nm), "gemm_nt_b16<%d,%d> K=%d N=%d", PRO, EPI, p.K, p.N);
+  const double ea = A16 ? 2.0 : 4.0, ec = C16 ? 2.0 : 4.0;
+  const double by = ea * (double)p.M * p.K * (PRO == PRO_GATE1 ? 0 : 1) +
+                    ec * (double)p.M * p.N * (EPI == EPI_GATE ? 3 : (EPI == EPI_DGRAD ? 2 : 1)) + 4.0 * (double)p.N * p.K;
+  ProfScope ps(nm, 2.0 * p.M * (double)p.N * p.K, by, st);
+  hipLaunchKernelGGL((gemm_nt_b16_kernel<PRO, EPI, A16, C16>), dim3((unsigned)(NTl * cdiv(p.M, 256))), dim3(512), lds, st,
+                     p, (const char*)(p.wprep + S3_WHDR));
+  LAUNCH_CHECK();
+  if (si) { si->count = 2 * cdiv(p.M, 256); si->rows = 128; }
+  return PRH_OK;
+}
+int g_b16_min_rows = [] { const char* e = getenv("PRH_B16_MIN_ROWS"); return e ? atoi(e) : 512; }();   // diagnostic
+inline bool nt_b16_generic_ok(const NTParams& p) {      // fp32-storage Linear served by the bf16 core in mode 4
+  return p.M >= g_b16_min_rows && p.wprep != nullptr && (p.K & 7) == 0 && p.K >= 64 && p.K <= 8192 && (p.lda & 3) == 0 && (p.N & 3) == 0 &&
+         (p.ldc & 3) == 0 && (p.E1 == nullptr || (p.lde1 & 3) == 0) && p.M >= 512 && p.N >= 64 &&
+         (long)cdiv(p.M, 256) * cdiv(p.N, 256) >= 16;
+}
+
+struct TNPlan16 { int tiles_m, tiles_n, splits, rows_per_split; };
+inline TNPlan16 tn_plan_b16(int P, int Mo, int Ni, long maxld) {
+  TNPlan16 pl;
+  pl.tiles_m = cdiv(Mo, 256); pl.tiles_n = cdiv(Ni, 256);
+  const int tiles = pl.tiles_m * pl.tiles_n;
+  int s = cdiv(768, tiles);
+  int best = s; double bw = 1e9;       // whole rounds of the 256 CUs (see tn_plan)
+  for (int c = (s > 3 ? s - 2 : 1); c <= s + 4; ++c) {
+    const double blocks = (double)tiles * c, w = (double)cdiv((long)blocks, 256L) * 256.0 / blocks;
+    if (w < bw - 1e-3) { bw = w; best = c; }
+  }
+  s = best;
+  const int smax = cdiv(P, 512) < 1 ? 1 : cdiv(P, 512);
+  if (s > smax) s = smax;
+  if (s < 1) s = 1;
+  int rps = cdiv(cdiv(P, s), TB_BK) * TB_BK;
+  if (rps < TB_BK) rps = TB_BK;
+  const int cap = (int)((2147483647L / (4L * (maxld < 4 ? 4 : maxld))) / TB_BK * TB_BK);   // 32-bit buffer offsets
+  if (rps > cap) rps = cap;
+  pl.splits = cdiv(P, rps) < 1 ? 1 : cdiv(P, rps);
+  pl.rows_per_split = rps;
+  return pl;
+}
+inline size_t tn16_splits_bound(int P, int Mo, int Ni) {
+  const size_t a = (size_t)tn_plan_b16(P, Mo, Ni, 4).splits, b = (size_t)tn_plan_b16(P, Mo, Ni, 8192).splits;
+  return a > b ? a : b;
+}
+inline size_t tn16_slab_floats(int P, int Mo, int Ni) { return tn16_splits_bound(P, Mo, Ni) * Mo * Ni + ABSMAX_MAX_BLOCKS + 64; }
+inline size_t tn16_colsum_floats(int P, int Mo, int Ni) { return tn16_splits_bound(P, Mo, Ni) * Mo; }
+
+// C[Mo,Ni] (ld ldc) = A^T proB(B), A [P,Mo] bf16, B [P,Ni] bf16 (GATE1: fp32 scalar per row);
+// colsum_out[Mo] = column sums of A (optional).  Slabs are fp32, summed in fp64.
+template <int PROB>
+int launch_tn_b16(TNParams& p, float* slab, float* colsum_slab, float* C, long ldc, float* colsum_out, hipStream_t st) {
+  if (p.Mo <= 0 || p.Ni <= 0) return PRH_OK;
+  if ((p.Mo & 7) || (p.Ni & 7) || (p.lda & 7) || (PROB != PRO_GATE1 && (p.ldb & 7)))
+    return fail(PRH_ERR_ARG, "gemm_tn_b16: Mo, Ni and the leading dimensions must be multiples of 8 (Mo=%d Ni=%d)", p.Mo, p.Ni);
+  long maxld = p.lda > p.ldb ? p.lda : p.ldb;
+  const TNPlan16 pl = tn_plan_b16(p.P, p.Mo, p.Ni, maxld);
+  p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n; p.splits = pl.splits; p.rows_per_split = pl.rows_per_split;
+  p.slab = slab;
+  p.colsum = colsum_out != nullptr ? colsum_slab : nullptr;
+  p.pace = nullptr; p.skew = 0;
+  if (g_tn_pace && pl.tiles_m * pl.tiles_n >= 8 && pl.splits <= ABSMAX_MAX_BLOCKS && pl.rows_per_split >= 16384) {
+    p.pace = reinterpret_cast<int*>(slab + (size_t)pl.splits * p.Mo * p.Ni + 64);
+    if (hipMemsetAsync(p.pace, 0, sizeof(int) * pl.splits, st) != hipSuccess)
+      return fail(PRH_ERR_HIP, "gemm_tn_b16: memset of the pacing counters failed");
+  }
+  const long blocks = (long)pl.tiles_m * pl.tiles_n * pl.splits;
+  static const int attr = allow_big_lds(gemm_tn_b16_kernel<PROB>);
+  if (attr != PRH_OK) return attr;
+  {
+    char nm[64];
+    snprintf(nm, sizeof(nm), "gemm_tn_b16<0,%d> Mo=%d Ni=%d", PROB, p.Mo, p.Ni);
+    const double by = 2.0 * (double)p.P * p.Mo + (PROB == PRO_GATE1 ? 4.0 * p.P : 2.0 * (double)p.P * p.Ni) + 4.0 * (double)p.Mo * p.Ni;
+    ProfScope ps(nm, 2.0 * p.P * (double)p.Mo * p.Ni, by, st);
+    hipLaunchKernelGGL((gemm_tn_b16_kernel<PROB>), dim3((unsigned)blocks), dim3(512), TB_LDS, st, p);
+    LAUNCH_CHECK();
+  }
+  if (C != nullptr && colsum_out != nullptr) {
+    const size_t len = (size_t)p.Mo * p.Ni + (size_t)p.Mo;
+    hipLaunchKernelGGL(slab_reduce2_kernel, dim3(cdiv((long)len, 256)), dim3(256), 0, st, slab, pl.splits, p.Mo, p.Ni, C,
+                       ldc, (const float*)colsum_slab, p.Mo, colsum_out);
+    LAUNCH_CHECK();
+    return PRH_OK;
+  }
+  if (C != nullptr) {
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv((long)p.Mo * p.Ni, 256)), dim3(256), 0, st, slab, pl.splits, p.Mo,
+                       p.Ni, C, ldc);
+    LAUNCH_CHECK();
+  }
+  if (colsum_out != nullptr) {
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(p.Mo, 256)), dim3(256), 0, st, colsum_slab, pl.splits, 1, p.Mo,
+                       colsum_out, (long)p.Mo);
+    LAUNCH_CHECK();
+  }
+  return PRH_OK;
+}
+
 // ------------------------------------------------------------------ launch helpers
 template <int PRO, int EPI>
 int launch_nt(NTParams& p, hipStream_t st, StatInfo* si = nullptr) {   // p.amaxA is filled in when measured
@@ -199,6 +324,9 @@ int launch_nt(NTParams& p, hipStream_t st, StatInfo* si = nullptr) {   // p.amax
       (PRO == PRO_BNBWD && (p.lda2 & 3)))
     return fail(PRH_ERR_ARG, "gemm_nt: K/lda/ldw must be multiples of 4 (K=%d lda=%ld ldw=%ld)",
                 p.K, p.lda, p.ldw);
+  if constexpr (PRO == PRO_NONE && EPI == EPI_BIAS) {
+    if (gemm_mode() == 4 && nt_b16_generic_ok(p)) return launch_nt_b16<PRO_NONE, EPI_BIAS, false, false>(p, st, si);
+  }
   char nm[64];
   // algorithmic traffic: A (+A2) read once, C written once (+E1/C_old reads), W read once
   const double by = 4.0 * ((double)p.M * p.K * (PRO == PRO_BNBWD ? 2 : (PRO == PRO_GATE1 ? 0 : 1)) +
@@ -209,7 +337,7 @@ int launch_nt(NTParams& p, hipStream_t st, StatInfo* si = nullptr) {   // p.amax
         !(EPI == EPI_GATE && ((p.N | (int)p.ldc | (int)p.lde1 | (int)p.ldc2) & 3) != 0)) {
       const int KT = cdiv(p.K, S3_BK), NTl = cdiv(p.N, S3_BN);
       const long th = (long)NTl * 256 * KT * 2;
-      const int mode = gemm_mode();
+      const int mode = core_mode();
       float* hdr = reinterpret_cast<float*>(p.wprep);
       const char* img = p.wprep + S3_WHDR;
       if (mode == 3) {      // operand scales of the fp16-plane core
@@ -362,7 +490,7 @@ int launch_tn(TNParams& p, float* slab, float* colsum_slab, float* C, long ldc, 
         if (attr_rc != PRH_OK) return attr_rc;
         if (attr_rc1 != PRH_OK) return attr_rc1;
         if (attr_rc2 != PRH_OK) return attr_rc2;
-        const int mode = gemm_mode();
+        const int mode = core_mode();
         if (mode == 3) {
           float* hdr = slab + (size_t)pl.splits * p.Mo * p.Ni;
           if (p.amaxA == nullptr) {
@@ -755,6 +883,75 @@ void enc_carve(Arena& a, EncWS& e, int P, const prh_bn_layer* conv, int cat, int
   e.gsum_b = a.f(64);
 }
 
+// ---- bf16 mode: workspace layouts and small launch helpers
+typedef unsigned short u16;
+struct Enc16WS {
+  u16* xpad; float* w0pad; float* ws_a; float* ws_b; double* stat2; char* wprep;
+  float *ca, *cb, *cc, *wT, *slab, *cslab, *dU, *gsum_a, *gsum_b; u16 *dy_cat, *dyf;
+};
+inline int cin_pad8(int c) { return (c + 7) / 8 * 8; }
+void enc16_carve(Arena& a, Enc16WS& e, int P, const int* ch /*[6]: cin, 64..od*/, int cat, int od, bool backward) {
+  const int c0p = cin_pad8(ch[0]);
+  const int maxc = cat > od ? cat : od;
+  e.xpad = (u16*)a.f(((size_t)P * c0p + 1) / 2);
+  e.w0pad = a.f((size_t)ch[1] * c0p);
+  e.ws_a = a.f((size_t)stat_tiles_max(P) * maxc);
+  e.ws_b = a.f((size_t)stat_tiles_max(P) * maxc);
+  e.stat2 = (double*)a.f((size_t)BN_SLICES * 3 * maxc * 2);
+  size_t wb = b16_weight_bytes(od, cat), t = b16_weight_bytes(cat, od);
+  wb = t > wb ? t : wb;
+  t = b16_weight_bytes(od, 64); wb = t > wb ? t : wb;
+  t = b16_weight_bytes(64, od); wb = t > wb ? t : wb;
+  for (int l = 0; l < 5; ++l) {
+    const int ci = l == 0 ? c0p : ch[l];
+    t = b16_weight_bytes(ch[l + 1], ci); wb = t > wb ? t : wb;
+    t = b16_weight_bytes(ci, ch[l + 1]); wb = t > wb ? t : wb;
+  }
+  e.wprep = (char*)a.f(wb / sizeof(float) + 64);
+  if (!backward) return;
+  e.ca = a.f(maxc); e.cb = a.f(maxc); e.cc = a.f(maxc);
+  e.wT = a.f((size_t)od * cat);
+  size_t sl = tn16_slab_floats(P, od, cat), cs = tn16_colsum_floats(P, od, cat);
+  t = tn16_slab_floats(P, od, 64); sl = t > sl ? t : sl;
+  t = tn16_colsum_floats(P, od, 64); cs = t > cs ? t : cs;
+  for (int l = 0; l < 5; ++l) {
+    const int ci = l == 0 ? c0p : ch[l];
+    t = tn16_slab_floats(P, ch[l + 1], ci); sl = t > sl ? t : sl;
+    t = tn16_colsum_floats(P, ch[l + 1], ci); cs = t > cs ? t : cs;
+  }
+  e.slab = a.f(sl); e.cslab = a.f(cs);
+  e.dy_cat = (u16*)a.f(((size_t)P * cat + 1) / 2);
+  e.dyf = (u16*)a.f(((size_t)P * od + 1) / 2);
+  e.dU = a.f((size_t)P * 64);
+  e.gsum_a = a.f(64); e.gsum_b = a.f(64);
+}
+int cast_b16(const float* src, long lds_, int cs, u16* dst, long ldd, int cd, size_t rows, hipStream_t st) {
+  const size_t n = rows * (size_t)(cd / 2);
+  if (n == 0) return PRH_OK;
+  hipLaunchKernelGGL(cast_b16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, lds_, cs, dst, ldd, cd, rows);
+  LAUNCH_CHECK();
+  return PRH_OK;
+}
+int bn_bwd_apply16(u16* dy, long lddy, const u16* z, long ldz, const float* ka, const float* kb, const float* kc,
+                   long rows, int cols, hipStream_t st) {
+  long blocks = cdiv(rows, 4L * 8);
+  blocks = blocks < 1 ? 1 : (blocks > ABSMAX_MAX_BLOCKS ? ABSMAX_MAX_BLOCKS : blocks);
+  hipLaunchKernelGGL(bn_bwd_apply_b16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dy, lddy, z, ldz, ka, kb, kc, rows, cols);
+  LAUNCH_CHECK();
+  return PRH_OK;
+}
+inline const float* f16p(const u16* p) { return reinterpret_cast<const float*>(p); }   // NTParams/TNParams carry typed-less pointers
+inline float* f16p(u16* p) { return reinterpret_cast<float*>(p); }
+struct Lin16WS { char* wprep; float* wT; float* slab; float* cslab; u16* dy16; };
+void lin16_carve(Arena& a, Lin16WS& w, int rows, int k, int n, bool backward) {
+  size_t wb = b16_weight_bytes(n, k), t = b16_weight_bytes(k, n);
+  w.wprep = (char*)a.f((t > wb ? t : wb) / sizeof(float) + 64);
+  if (!backward) return;
+  w.wT = a.f((size_t)k * n);
+  w.slab = a.f(tn16_slab_floats(rows, n, k));
+  w.cslab = a.f(tn16_colsum_floats(rows, n, k));
+  w.dy16 = (u16*)a.f(((size_t)rows * n + 1) / 2);
+}
 }  // namespace
 
 // =======================================================================================
@@ -762,8 +959,8 @@ extern "C" {
 
 const char* prh_last_error(void) { return g_err; }
 int prh_set_gemm_mode(int mode) {
-  if (mode < 0 || mode > 3)
-    return fail(PRH_ERR_ARG, "gemm mode must be 0 (fp32), 1 (split-bf16), 2 (bf16) or 3 (split-fp16)");
+  if (mode < 0 || mode > 4)
+    return fail(PRH_ERR_ARG, "gemm mode must be 0 (fp32), 1 (split-bf16), 2 (bf16 operands), 3 (split-fp16) or 4 (bf16 operands and storage)");
   g_gemm_mode = mode;
   return PRH_OK;
 }
@@ -1282,6 +1479,262 @@ int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B,
                          prm->gate_w1, d_ctx, (long)C);
       LAUNCH_CHECK();
     }
+  }
+  return PRH_OK;
+}
+
+// ------------------------------------------------------------------ bf16 mode (BASELINE config 3)
+// Encoder with bf16 activation storage on the bf16 cores (prh_b16.hpp); same arithmetic and
+// the same order of operations as prh_encoder_forward / prh_encoder_backward.
+
+size_t prh_encoder_bf16_workspace_bytes(int B, int N, int in_channel, int out_dim, int backward) {
+  const int ch[6] = {in_channel, 64, 128, 256, 512, out_dim};
+  Arena a; Enc16WS e;
+  enc16_carve(a, e, B * N, ch, 64 + 128 + 256 + 512 + out_dim, out_dim, backward != 0);
+  return a.off + 256;
+}
+
+int prh_encoder_forward_bf16(const prh_encoder_params* prm, const float* ctx, int B, int N, int training,
+                             float momentum, float eps, uint16_t* fused, float* gfeat,
+                             const prh_encoder_saved_bf16* sv, void* workspace, size_t workspace_bytes,
+                             int device, void* stream) {
+  TRY(check_encoder(prm));
+  if (!ctx || !fused || !sv || !sv->z_cat || !sv->z_fus || !sv->bn_scale || !sv->bn_shift || !sv->bn_mean ||
+      !sv->bn_rstd || B <= 0 || N <= 0)
+    return fail(PRH_ERR_ARG, "encoder_forward_bf16: bad argument");
+  if ((long)B * N > 1000000000L) return fail(PRH_ERR_ARG, "encoder_forward_bf16: B*N too large");
+  const int P = B * N;
+  if (training && P < 2) return fail(PRH_ERR_ARG, "Expected more than 1 value per channel when training");
+  for (int l = 0; l < 5; ++l)
+    if (prm->conv[l].cout % 8) return fail(PRH_ERR_ARG, "encoder_forward_bf16: channel widths must be multiples of 8");
+  if (prm->out_dim % 8) return fail(PRH_ERR_ARG, "encoder_forward_bf16: out_dim must be a multiple of 8");
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  const int cat = enc_cat(prm), od = prm->out_dim, C = prm->in_channel, c0p = cin_pad8(C);
+  const int ch[6] = {C, prm->conv[0].cout, prm->conv[1].cout, prm->conv[2].cout, prm->conv[3].cout, od};
+  Arena a(workspace, workspace_bytes);
+  Enc16WS w;
+  enc16_carve(a, w, P, ch, cat, od, false);
+  if (!a.ok) return fail(PRH_ERR_WORKSPACE, "encoder_forward_bf16: workspace too small (%zu bytes)", workspace_bytes);
+  StackDims d = stack_dims(prm->conv, 5);
+  u16* z_cat = sv->z_cat;
+  // context rows -> bf16, padded to a multiple of 8 channels; conv1's weight padded alike
+  TRY(cast_b16(ctx, C, C, w.xpad, c0p, c0p, (size_t)P, st));
+  TRY(copy_cols(prm->conv[0].w, C, C, w.w0pad, c0p, c0p, (size_t)prm->conv[0].cout, st));
+  for (int l = 0; l < 5; ++l) {                       // conv1..5, BN+ReLU applied on load by the consumer
+    const prh_bn_layer& ly = prm->conv[l];
+    NTParams p; memset(&p, 0, sizeof(p));
+    p.M = P; p.N = ly.cout; p.bias = ly.b; p.C = f16p(z_cat + d.off[l]); p.ldc = cat;
+    p.ws_a = w.ws_a; p.ws_b = w.ws_b; p.wprep = w.wprep;
+    StatInfo si;
+    if (l == 0) {
+      p.A = f16p(w.xpad); p.lda = c0p; p.W = w.w0pad; p.ldw = c0p; p.K = c0p;
+      if (training) TRY((launch_nt_b16<PRO_NONE, EPI_BIAS_STATS, true, true>(p, st, &si)));
+      else TRY((launch_nt_b16<PRO_NONE, EPI_BIAS, true, true>(p, st)));
+    } else {
+      p.A = f16p(z_cat + d.off[l - 1]); p.lda = cat; p.W = ly.w; p.ldw = ly.cin; p.K = ly.cin;
+      p.pa = sv->bn_scale + d.off[l - 1]; p.pb = sv->bn_shift + d.off[l - 1];
+      if (training) TRY((launch_nt_b16<PRO_BNRELU, EPI_BIAS_STATS, true, true>(p, st, &si)));
+      else TRY((launch_nt_b16<PRO_BNRELU, EPI_BIAS, true, true>(p, st)));
+    }
+    TRY(bn_coeffs(ly, P, training, momentum, eps, w.ws_a, w.ws_b, w.stat2, si, sv->bn_mean + d.off[l],
+                  sv->bn_rstd + d.off[l], sv->bn_scale + d.off[l], sv->bn_shift + d.off[l], st));
+  }
+  {                                                   // fusion conv over the virtual concat
+    NTParams p; memset(&p, 0, sizeof(p));
+    p.A = f16p(z_cat); p.lda = cat; p.W = prm->fusion.w; p.ldw = cat; p.K = cat;
+    p.pa = sv->bn_scale; p.pb = sv->bn_shift;
+    p.M = P; p.N = od; p.bias = prm->fusion.b; p.C = f16p(sv->z_fus); p.ldc = od;
+    p.ws_a = w.ws_a; p.ws_b = w.ws_b; p.wprep = w.wprep;
+    StatInfo si;
+    if (training) TRY((launch_nt_b16<PRO_BNRELU, EPI_BIAS_STATS, true, true>(p, st, &si)));
+    else TRY((launch_nt_b16<PRO_BNRELU, EPI_BIAS, true, true>(p, st)));
+    TRY(bn_coeffs(prm->fusion, P, training, momentum, eps, w.ws_a, w.ws_b, w.stat2, si, sv->bn_mean + cat,
+                  sv->bn_rstd + cat, sv->bn_scale + cat, sv->bn_shift + cat, st));
+  }
+  {                                                   // intensity gate GEMM + BN/ReLU/gate combine
+    NTParams p; memset(&p, 0, sizeof(p));
+    p.A = ctx + 3; p.lda = C; p.pa = prm->gate_w1; p.pb = prm->gate_b1;
+    p.W = prm->gate_w2; p.ldw = 64; p.K = 64; p.M = P; p.N = od; p.bias = prm->gate_b2;
+    p.E1 = f16p(sv->z_fus); p.lde1 = od; p.es = sv->bn_scale + cat; p.et = sv->bn_shift + cat;
+    p.C = f16p(fused); p.ldc = od; p.C2 = f16p(sv->gate); p.ldc2 = od;
+    p.wprep = w.wprep;
+    p.flags = sv->gate ? F_STORE_GATE : 0;
+    TRY((launch_nt_b16<PRO_GATE1, EPI_GATE, true, true>(p, st)));
+  }
+  if (gfeat != nullptr) {
+    hipLaunchKernelGGL(pool_b16_kernel, dim3(cdiv(od, 64), B), dim3(256), 0, st, (const u16*)fused, N, od, gfeat, sv->argmax);
+    LAUNCH_CHECK();
+  }
+  return PRH_OK;
+}
+
+int prh_encoder_backward_bf16(const prh_encoder_params* prm, const float* ctx, int B, int N, int training,
+                              const uint16_t* d_fused, const float* d_gfeat, const prh_encoder_saved_bf16* sv,
+                              const prh_encoder_grads* gr, float* d_ctx, void* workspace, size_t workspace_bytes,
+                              int device, void* stream) {
+  TRY(check_encoder(prm));
+  if (!ctx || !sv || !gr || !sv->z_cat || !sv->z_fus || !sv->gate || (!d_fused && !d_gfeat) || B <= 0 || N <= 0)
+    return fail(PRH_ERR_ARG, "encoder_backward_bf16: bad argument (a gradient and saved.gate are required)");
+  if (d_gfeat && !sv->argmax) return fail(PRH_ERR_ARG, "encoder_backward_bf16: d_gfeat needs saved.argmax");
+  const int P = B * N;
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  const int cat = enc_cat(prm), od = prm->out_dim, C = prm->in_channel, c0p = cin_pad8(C);
+  const int ch[6] = {C, prm->conv[0].cout, prm->conv[1].cout, prm->conv[2].cout, prm->conv[3].cout, od};
+  Arena a(workspace, workspace_bytes);
+  Enc16WS w;
+  enc16_carve(a, w, P, ch, cat, od, true);
+  if (!a.ok) return fail(PRH_ERR_WORKSPACE, "encoder_backward_bf16: workspace too small (%zu bytes)", workspace_bytes);
+  StackDims d = stack_dims(prm->conv, 5);
+  const u16* z_cat = sv->z_cat;
+  TRY(cast_b16(ctx, C, C, w.xpad, c0p, c0p, (size_t)P, st));
+  TRY(copy_cols(prm->conv[0].w, C, C, w.w0pad, c0p, c0p, (size_t)prm->conv[0].cout, st));
+
+  // (1) through F = relu(bn(zf)) * m and the pooling: dy_f, dG (over saved.gate), fusion-BN partials
+  hipLaunchKernelGGL(combine_bwd_b16_kernel, dim3(cdiv(P, 64), cdiv(od, 64)), dim3(256), 0, st, (const u16*)d_fused,
+                     d_gfeat, sv->argmax, (const u16*)sv->z_fus, (u16*)sv->gate, sv->bn_scale + cat, sv->bn_shift + cat,
+                     P, N, od, w.dyf, w.ws_a, w.ws_b);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_stage1_kernel, dim3(cdiv(od, 32), BN_SLICES), dim3(256), 0, st, w.ws_a, w.ws_b, cdiv(P, 64),
+                     (long)od, od, 64, P, 0, w.stat2);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(od, 128)), dim3(128), 0, st, w.stat2, P, od, prm->fusion.gamma,
+                     sv->bn_mean + cat, sv->bn_rstd + cat, training, w.ca, w.cb, w.cc, gr->fusion.dgamma,
+                     gr->fusion.dbeta, gr->fusion.db);
+  LAUNCH_CHECK();
+  u16* dG = sv->gate;
+  // (2) fusion conv: dz_f in place, wgrad over the virtual concat, dgrad into dy_cat (masked per layer)
+  TRY(bn_bwd_apply16(w.dyf, od, sv->z_fus, od, w.ca, w.cb, w.cc, P, od, st));
+  if (gr->fusion.dw) {
+    TNParams t; memset(&t, 0, sizeof(t));
+    t.A = f16p(w.dyf); t.lda = od; t.B = f16p(z_cat); t.ldb = cat; t.qa = sv->bn_scale; t.qb = sv->bn_shift;
+    t.P = P; t.Mo = od; t.Ni = cat;
+    TRY((launch_tn_b16<PRO_BNRELU>(t, w.slab, w.cslab, gr->fusion.dw, (long)cat, nullptr, st)));
+  }
+  StatInfo si;
+  {
+    TRY(transpose(prm->fusion.w, od, cat, w.wT, st));   // [cat, od]
+    NTParams p; memset(&p, 0, sizeof(p));
+    p.A = f16p(w.dyf); p.lda = od; p.W = w.wT; p.ldw = od; p.M = P; p.N = cat; p.K = od;
+    p.C = f16p(w.dy_cat); p.ldc = cat; p.E1 = f16p(z_cat); p.lde1 = cat; p.es = sv->bn_scale; p.et = sv->bn_shift;
+    p.wprep = w.wprep; p.ws_a = w.ws_a; p.ws_b = w.ws_b;
+    p.flags = F_MASK | F_STATS;
+    TRY((launch_nt_b16<PRO_NONE, EPI_DGRAD, true, true>(p, st, &si)));
+    si.ld = cat; si.off = d.off[4];
+  }
+  // (3) conv5..conv1
+  for (int l = 4; l >= 0; --l) {
+    const prh_bn_layer& ly = prm->conv[l];
+    const int co = ly.cout, o = d.off[l];
+    hipLaunchKernelGGL(bn_stage1_kernel, dim3(cdiv(co, 32), BN_SLICES), dim3(256), 0, st, w.ws_a + si.off, w.ws_b + si.off,
+                       si.count, si.ld ? si.ld : (long)co, co, 64, P, 0, w.stat2);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(co, 128)), dim3(128), 0, st, w.stat2, P, co, ly.gamma,
+                       sv->bn_mean + o, sv->bn_rstd + o, training, w.ca, w.cb, w.cc, gr->conv[l].dgamma,
+                       gr->conv[l].dbeta, gr->conv[l].db);
+    LAUNCH_CHECK();
+    TRY(bn_bwd_apply16(w.dy_cat + o, cat, z_cat + o, cat, w.ca, w.cb, w.cc, P, co, st));
+    if (gr->conv[l].dw) {
+      TNParams t; memset(&t, 0, sizeof(t));
+      t.A = f16p(w.dy_cat + o); t.lda = cat; t.P = P; t.Mo = co;
+      if (l == 0) {
+        t.B = f16p(w.xpad); t.ldb = c0p; t.Ni = c0p;
+        float* out = c0p == C ? gr->conv[0].dw : w.wT;        // padded input: reduce into scratch, drop the pad columns
+        TRY((launch_tn_b16<PRO_NONE>(t, w.slab, w.cslab, out, (long)c0p, nullptr, st)));
+        if (c0p != C) TRY(copy_cols(w.wT, c0p, C, gr->conv[0].dw, C, C, (size_t)co, st));
+      } else {
+        t.B = f16p(z_cat + d.off[l - 1]); t.ldb = cat; t.Ni = ly.cin;
+        t.qa = sv->bn_scale + d.off[l - 1]; t.qb = sv->bn_shift + d.off[l - 1];
+        TRY((launch_tn_b16<PRO_BNRELU>(t, w.slab, w.cslab, gr->conv[l].dw, (long)ly.cin, nullptr, st)));
+      }
+    }
+    if (l > 0) {
+      TRY(transpose(ly.w, co, ly.cin, w.wT, st));        // wT [cin, cout]
+      NTParams p; memset(&p, 0, sizeof(p));
+      p.A = f16p(w.dy_cat + o); p.lda = cat; p.W = w.wT; p.ldw = co; p.M = P; p.N = ly.cin; p.K = co;
+      p.C = f16p(w.dy_cat + d.off[l - 1]); p.ldc = cat;
+      p.E1 = f16p(z_cat + d.off[l - 1]); p.lde1 = cat;
+      p.es = sv->bn_scale + d.off[l - 1]; p.et = sv->bn_shift + d.off[l - 1];
+      p.ws_a = w.ws_a; p.ws_b = w.ws_b; p.wprep = w.wprep;
+      p.flags = F_ACCUM | F_MASK | F_STATS;
+      TRY((launch_nt_b16<PRO_NONE, EPI_DGRAD, true, true>(p, st, &si)));
+      si.ld = 0; si.off = 0;
+    } else if (d_ctx != nullptr) {
+      TRY(transpose(w.w0pad, co, c0p, w.wT, st));        // [c0p, cout], zero pad rows
+      NTParams p; memset(&p, 0, sizeof(p));
+      p.A = f16p(w.dy_cat + o); p.lda = cat; p.W = w.wT; p.ldw = co; p.M = P; p.N = C; p.K = co;
+      p.C = d_ctx; p.ldc = C; p.wprep = w.wprep; p.flags = 0;
+      if (C % 4) return fail(PRH_ERR_ARG, "encoder_backward_bf16: d_ctx needs in_channel %% 4 == 0");
+      TRY((launch_nt_b16<PRO_NONE, EPI_DGRAD, true, false>(p, st)));
+    }
+  }
+  // (4) intensity gate: dW2 = dG^T u, db2 = colsum dG; dU = dG W2 masked by u > 0 with column
+  //     sums (db1) and intensity-weighted column sums (dw1)
+  {
+    TNParams t; memset(&t, 0, sizeof(t));
+    t.A = f16p(dG); t.lda = od; t.B = ctx + 3; t.ldb = C; t.qa = prm->gate_w1; t.qb = prm->gate_b1;
+    t.P = P; t.Mo = od; t.Ni = 64;
+    TRY((launch_tn_b16<PRO_GATE1>(t, w.slab, w.cslab, gr->d_gate_w2, 64L, gr->d_gate_b2, st)));
+    TRY(transpose(prm->gate_w2, od, 64, w.wT, st));   // [64, od]
+    NTParams p; memset(&p, 0, sizeof(p));
+    p.A = f16p(dG); p.lda = od; p.W = w.wT; p.ldw = od; p.M = P; p.N = 64; p.K = od;
+    p.C = w.dU; p.ldc = 64; p.E1 = ctx + 3; p.lde1 = C; p.es = prm->gate_w1; p.et = prm->gate_b1;
+    p.ws_a = w.ws_a; p.ws_b = w.ws_b; p.wprep = w.wprep;
+    p.flags = F_MASK | F_STATS | F_E1_ROWVEC;
+    StatInfo sig;
+    TRY((launch_nt_b16<PRO_NONE, EPI_DGRAD, true, false>(p, st, &sig)));
+    hipLaunchKernelGGL(partials_reduce_kernel, dim3(2), dim3(1024), 0, st, w.ws_a, w.ws_b, sig.count, 64,
+                       gr->d_gate_b1 ? gr->d_gate_b1 : w.gsum_a, gr->d_gate_w1 ? gr->d_gate_w1 : w.gsum_b);
+    LAUNCH_CHECK();
+    if (d_ctx != nullptr) {
+      hipLaunchKernelGGL(gate1_dctx_kernel, dim3(cdiv(P, 4)), dim3(256), 0, st, w.dU, P, 64, prm->gate_w1, d_ctx, (long)C);
+      LAUNCH_CHECK();
+    }
+  }
+  return PRH_OK;
+}
+
+// nn.Linear whose input is a bf16 activation (context_proj on the bf16 `fused`): y fp32
+size_t prh_linear_bf16_workspace_bytes(int rows, int k, int n, int backward) {
+  Arena a; Lin16WS w;
+  lin16_carve(a, w, rows, k, n, backward != 0);
+  return a.off + 256;
+}
+int prh_linear_forward_bf16(const uint16_t* x, long ldx, const float* w, const float* b, float* y, int rows, int k,
+                            int n, int relu, void* workspace, size_t workspace_bytes, int device, void* stream) {
+  if (!x || !w || !y || rows < 0 || k <= 0 || n <= 0) return fail(PRH_ERR_ARG, "linear_forward_bf16: bad argument");
+  HIP_TRY(hipSetDevice(device));
+  Arena a(workspace, workspace_bytes); Lin16WS lw;
+  lin16_carve(a, lw, rows, k, n, false);
+  if (!a.ok) return fail(PRH_ERR_WORKSPACE, "linear_forward_bf16: workspace too small (%zu bytes)", workspace_bytes);
+  NTParams p; memset(&p, 0, sizeof(p));
+  p.A = f16p(x); p.lda = ldx; p.W = w; p.ldw = k; p.C = y; p.ldc = n; p.M = rows; p.N = n; p.K = k; p.bias = b;
+  p.flags = relu ? F_RELU_OUT : 0; p.wprep = lw.wprep;
+  return launch_nt_b16<PRO_NONE, EPI_BIAS, true, false>(p, (hipStream_t)stream);
+}
+int prh_linear_backward_bf16(const uint16_t* x, long ldx, const float* w, const float* dy, uint16_t* dx, float* dw,
+                             float* db, int rows, int k, int n, void* workspace, size_t workspace_bytes, int device,
+                             void* stream) {
+  if (!x || !w || !dy || rows < 0 || k <= 0 || n <= 0) return fail(PRH_ERR_ARG, "linear_backward_bf16: bad argument");
+  if ((k & 7) || (n & 7)) return fail(PRH_ERR_ARG, "linear_backward_bf16: k=%d and n=%d must be multiples of 8", k, n);
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  Arena a(workspace, workspace_bytes); Lin16WS lw;
+  lin16_carve(a, lw, rows, k, n, true);
+  if (!a.ok) return fail(PRH_ERR_WORKSPACE, "linear_backward_bf16: workspace too small (%zu bytes)", workspace_bytes);
+  TRY(cast_b16(dy, n, n, lw.dy16, n, n, (size_t)rows, st));      // one operand for both GEMMs
+  if (dx != nullptr) {
+    TRY(transpose(w, n, k, lw.wT, st));   // wT [k, n]
+    NTParams p; memset(&p, 0, sizeof(p));
+    p.A = f16p(lw.dy16); p.lda = n; p.W = lw.wT; p.ldw = n; p.C = f16p(dx); p.ldc = k; p.M = rows; p.N = k; p.K = n;
+    p.wprep = lw.wprep;
+    TRY((launch_nt_b16<PRO_NONE, EPI_BIAS, true, true>(p, st)));
+  }
+  if (dw != nullptr || db != nullptr) {
+    TNParams t; memset(&t, 0, sizeof(t));
+    t.A = f16p(lw.dy16); t.lda = n; t.B = f16p(x); t.ldb = ldx; t.P = rows; t.Mo = n; t.Ni = k;
+    TRY((launch_tn_b16<PRO_NONE>(t, lw.slab, lw.cslab, dw, (long)k, db, st)));
   }
   return PRH_OK;
 }

@@ -129,6 +129,8 @@ class MultiScalePointNetEncoder(nn.Module):
         if x.dim() != 3:
             raise RuntimeError(f"Expected 3D (batched) input, but got input of size: {list(x.shape)}")
         gfeat, fused = self.forward_pointmajor(x.transpose(2, 1).contiguous(), True)
+        if fused.dtype != x.dtype:              # bf16 mode keeps `fused` in bf16; the API contract is the input's dtype
+            fused = fused.to(x.dtype)
         return gfeat, fused.transpose(2, 1)
 
 

@@ -75,6 +75,8 @@ class LinearFn(torch.autograd.Function):
         operand for the split-fp16 core; e.g. the encoder's bound for its output).  relu: apply
         ReLU in the GEMM epilogue (the backward masks dy with y > 0).  resid: tensor of the output's
         shape added in the epilogue, y = act(x W^T + b + resid)."""
+        if x.dtype == torch.bfloat16:
+            return LinearFn._forward_bf16(ctx, x, w, b, relu, resid)
         _req_gpu_f32(x, "input")
         _req_gpu_f32(w, "weight")
         n, k = w.shape
@@ -82,6 +84,7 @@ class LinearFn(torch.autograd.Function):
             raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({x.shape} and {k}x{n})")
         if k % 4:
             raise RuntimeError("pointnet_refine_amd.linear: in_features must be a multiple of 4")
+        ctx.bf16_in = False
         x2 = x.reshape(-1, k)
         if not x2.is_contiguous():
             x2 = x2.contiguous()
@@ -121,7 +124,46 @@ class LinearFn(torch.autograd.Function):
         return y.reshape(*x.shape[:-1], n)
 
     @staticmethod
+    def _forward_bf16(ctx, x, w, b, relu, resid):
+        """x is a bf16 activation of the bf16 mode (the encoder's `fused`): y fp32 on the bf16 core."""
+        if not x.is_cuda:
+            raise RuntimeError("pointnet_refine_amd.linear: bf16 input must be a GPU tensor")
+        _req_gpu_f32(w, "weight")
+        n, k = w.shape
+        if x.shape[-1] != k or k % 8 or n % 8 or resid is not None or relu:
+            raise RuntimeError("pointnet_refine_amd.linear (bf16 input): needs in/out features % 8 == 0, no residual, no ReLU")
+        x2 = x.reshape(-1, k)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        w = w.contiguous()
+        rows = x2.shape[0]
+        y = torch.empty((rows, n), dtype=torch.float32, device=x.device)
+        ws = _ws(x.device, L.lib().prh_linear_bf16_workspace_bytes(rows, k, n, 0))
+        L.check(L.lib().prh_linear_forward_bf16(_p(x2), k, _p(w), _p(b), _p(y), rows, k, n, 0, _p(ws), ws.numel(),
+                                                x.device.index, _stream(x.device)), "prh_linear_forward_bf16")
+        ctx.save_for_backward(x2, w)
+        ctx.bf16_in, ctx.relu, ctx.has_resid, ctx.has_bias, ctx.xshape = True, False, False, b is not None, x.shape
+        return y.reshape(*x.shape[:-1], n)
+
+    @staticmethod
+    def _backward_bf16(ctx, dy):
+        x2, w = ctx.saved_tensors
+        n, k = w.shape
+        rows, dev = x2.shape[0], x2.device
+        dy2 = dy.reshape(rows, n).float().contiguous()
+        need_dx, need_dw, need_db = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        dx = torch.empty_like(x2) if need_dx else None
+        dw = torch.empty_like(w) if need_dw else None
+        db = torch.empty(n, dtype=torch.float32, device=dev) if need_db else None
+        ws = _ws(dev, L.lib().prh_linear_bf16_workspace_bytes(rows, k, n, 1))
+        L.check(L.lib().prh_linear_backward_bf16(_p(x2), k, _p(w), _p(dy2), _p(dx), _p(dw), _p(db), rows, k, n, _p(ws),
+                                                 ws.numel(), dev.index, _stream(dev)), "prh_linear_backward_bf16")
+        return (dx.reshape(ctx.xshape) if need_dx else None), dw, db, None, None, None
+
+    @staticmethod
     def backward(ctx, dy):
+        if ctx.bf16_in:
+            return LinearFn._backward_bf16(ctx, dy)
         if ctx.relu:
             x2, w, y = ctx.saved_tensors
         else:
@@ -409,6 +451,9 @@ class EncoderFn(torch.autograd.Function):
         cat = 64 + 128 + 256 + 512 + out_dim
         P = B * N
         need_bwd = any(ctx.needs_input_grad)
+        ctx.bf16 = L.lib().prh_get_gemm_mode() == 4
+        if ctx.bf16:
+            return EncoderFn._forward_bf16(ctx, x, want_global, training, momentum, eps, buffers, params, p2, need_bwd)
         z_cat = torch.empty((P, cat), dtype=torch.float32, device=dev)
         z_fus = torch.empty((P, out_dim), dtype=torch.float32, device=dev)
         gate = torch.empty((P, out_dim), dtype=torch.float32, device=dev) if need_bwd else None
@@ -441,11 +486,78 @@ class EncoderFn(torch.autograd.Function):
         return None, fused
 
     @staticmethod
+    def _forward_bf16(ctx, x, want_global, training, momentum, eps, buffers, params, p2, need_bwd):
+        """Mode 4 (BASELINE config 3): activations kept for the backward, and `fused` itself, in bf16."""
+        dev = x.device
+        B, N, Cin = x.shape
+        out_dim = p2[8].shape[0]
+        cat = 64 + 128 + 256 + 512 + out_dim
+        P = B * N
+        bf = torch.bfloat16
+        z_cat = torch.empty((P, cat), dtype=bf, device=dev)
+        z_fus = torch.empty((P, out_dim), dtype=bf, device=dev)
+        gate = torch.empty((P, out_dim), dtype=bf, device=dev) if need_bwd else None
+        coef = torch.empty((4, cat + out_dim), dtype=torch.float32, device=dev)
+        fused = torch.empty((B, N, out_dim), dtype=bf, device=dev)
+        gfeat = torch.empty((B, 2 * out_dim), dtype=torch.float32, device=dev) if want_global else None
+        argmax = torch.empty((B, out_dim), dtype=torch.int32, device=dev) if (want_global and need_bwd) else None
+        prm = _enc_params_struct(p2, buffers, Cin)
+        sv = L.EncoderSavedBf16(_p(z_cat), _p(z_fus), _p(gate), _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]),
+                                _p(argmax))
+        nb = L.lib().prh_encoder_bf16_workspace_bytes(B, N, Cin, out_dim, 0)
+        ws = _ws(dev, nb)
+        L.check(L.lib().prh_encoder_forward_bf16(C.byref(prm), _p(x), B, N, int(training), float(momentum), float(eps),
+                                                 _p(fused), _p(gfeat), C.byref(sv), _p(ws), ws.numel(), dev.index,
+                                                 _stream(dev)), "prh_encoder_forward_bf16")
+        if need_bwd:
+            ctx.save_for_backward(x, z_cat, z_fus, gate, coef, argmax if argmax is not None else coef, *p2)
+            ctx.has_argmax = argmax is not None
+            ctx.training = int(training)
+            ctx.pshapes = [t.shape for t in params]
+            ctx.consumed = False
+        EncoderFn.last_fused_amax = None
+        return (gfeat if want_global else None), fused
+
+    @staticmethod
+    def _backward_bf16(ctx, d_gfeat, d_fused):
+        saved = ctx.saved_tensors
+        x, z_cat, z_fus, gate, coef, argmax = saved[:6]
+        p2 = list(saved[6:])
+        dev = x.device
+        B, N, Cin = x.shape
+        out_dim = p2[8].shape[0]
+        if d_fused is not None:
+            d_fused = d_fused.to(torch.bfloat16).contiguous()
+        if d_gfeat is not None:
+            if not ctx.has_argmax:
+                raise RuntimeError("encoder backward: gradient for global_feat but no argmax saved")
+            d_gfeat = d_gfeat.float().contiguous()
+        prm = _enc_params_struct(p2, None, Cin)
+        sv = L.EncoderSavedBf16(_p(z_cat), _p(z_fus), _p(gate), _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]),
+                                _p(argmax) if ctx.has_argmax else None)
+        g = [torch.empty_like(t) for t in p2]
+        gr = L.EncoderGrads()
+        for k in range(5):
+            gr.conv[k] = L.BnLayerGrad(_p(g[2 * k]), _p(g[2 * k + 1]), _p(g[10 + 2 * k]), _p(g[11 + 2 * k]))
+        gr.fusion = L.BnLayerGrad(_p(g[20]), _p(g[21]), _p(g[22]), _p(g[23]))
+        gr.d_gate_w1, gr.d_gate_b1, gr.d_gate_w2, gr.d_gate_b2 = _p(g[24]), _p(g[25]), _p(g[26]), _p(g[27])
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        nb = L.lib().prh_encoder_bf16_workspace_bytes(B, N, Cin, out_dim, 1)
+        ws = _ws(dev, nb)
+        L.check(L.lib().prh_encoder_backward_bf16(C.byref(prm), _p(x), B, N, ctx.training, _p(d_fused), _p(d_gfeat),
+                                                  C.byref(sv), C.byref(gr), _p(dx), _p(ws), ws.numel(), dev.index,
+                                                  _stream(dev)), "prh_encoder_backward_bf16")
+        grads = [gi.reshape(s) for gi, s in zip(g, ctx.pshapes)]
+        return (dx, None, None, None, None, None, *grads)
+
+    @staticmethod
     def backward(ctx, d_gfeat, d_fused):
         if ctx.consumed:
             raise RuntimeError("pointnet_refine_amd encoder: backward through the same graph a second "
                                "time is not supported (saved activations are consumed in place)")
         ctx.consumed = True
+        if ctx.bf16:
+            return EncoderFn._backward_bf16(ctx, d_gfeat, d_fused)
         saved = ctx.saved_tensors
         x, z_cat, z_fus, gate, coef, argmax = saved[:6]
         p2 = list(saved[6:])

@@ -1,0 +1,52 @@
+"""Where does the bf16 mode's output error come from?  Train-mode forward on the G2 inputs
+(dropout off) with encoder side / decoder side in different GEMM modes, against the exact-fp32
+cores.  python scripts/bf16_error_budget.py  (on the GPU box)"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import procedural as P
+from pointnet_refine_amd import _lib
+from pointnet_refine_amd.model import LineRefineNet
+
+lib = _lib.lib()
+
+
+def model():
+    m = LineRefineNet()
+    m.load_state_dict(P.linerefine_state_dict(0), strict=True)
+    m = m.cuda().train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        if isinstance(mod, torch.nn.MultiheadAttention):
+            mod.dropout = 0.0
+    return m
+
+
+def run(B, N, enc_mode, dec_mode, seed=1234):
+    ctx, noisy, _ = P.synth_batch(B, N, 4, 32, seed=seed)
+    ctx, noisy = ctx.cuda(), noisy.cuda()
+    m = model()
+    with torch.no_grad():
+        lib.prh_set_gemm_mode(enc_mode)
+        memory = m.encode_context(ctx)
+        tgt = m.encode_line(noisy)
+        lib.prh_set_gemm_mode(dec_mode)
+        out = m.decode(ctx, noisy, memory, tgt)
+    return memory.float(), tgt, out
+
+
+for B, N in ((64, 1024),):
+    ref = run(B, N, 0, 0)
+    print(f"B={B} N={N}")
+    for name, em, dm in (("all bf16 (mode 4)", 4, 4), ("encoder bf16 storage, decoder split16", 4, 3),
+                         ("encoder split16, decoder bf16 operands", 3, 4), ("round-1 bf16 operands, fp32 storage (mode 2)", 2, 2),
+                         ("encoder mode 2, decoder split16", 2, 3), ("split16 everywhere", 3, 3)):
+        mem, tgt, out = run(B, N, em, dm)
+        print(f"  {name:48s} memory rel-L2 {float((mem - ref[0]).norm() / ref[0].norm()):.3e}  "
+              f"tgt0 rel-L2 {float((tgt - ref[1]).norm() / ref[1].norm()):.3e}  out max-abs {float((out - ref[2]).abs().max()):.3e}  "
+              f"out rel-L2 {float((out - ref[2]).norm() / ref[2].norm()):.3e}")
+lib.prh_set_gemm_mode(3)
