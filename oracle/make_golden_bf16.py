@@ -22,8 +22,38 @@ from oracle.make_golden import import_reference, zero_dropout, maxdiff, rel_l2, 
 
 
 def main():
-    LineRefineNet, _ = import_reference()
+    LineRefineNet, Encoder = import_reference()
     out = {}
+    # ---- encoder alone, G3 set-up (tests/test_encoder_gpu.py): both returns, random upstream gradients
+    B, N, Cc = 4, 192, 4
+    esd = P.encoder_state_dict(Cc, 1024, seed=3)
+    esd["fusion.1.weight"][5] = 0.0
+    esd["fusion.1.bias"][5] = -1.0
+    ectx, _, _ = P.synth_batch(B, N, Cc, 32, seed=77)
+    r = np.random.default_rng(5)
+    up_g = torch.from_numpy(r.normal(0, 1, (B, 2048)).astype(np.float32))
+    up_f = torch.from_numpy(r.normal(0, 1, (B, N, 1024)).astype(np.float32))
+
+    def enc(train, autocast):
+        m = Encoder(in_channel=Cc, out_dim=1024)
+        m.load_state_dict(esd, strict=True)
+        m.train(train)
+        x = ectx.clone().requires_grad_(True)
+        with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
+            gf, fu = m(x.transpose(2, 1))
+        ((gf.float() * up_g).sum() + (fu.float().transpose(2, 1) * up_f).sum()).backward()
+        return gf.float().detach(), fu.float().detach(), x.grad.detach(), {k: p.grad.detach().float() for k, p in m.named_parameters()}
+
+    for train in (False, True):
+        a, b = enc(train, False), enc(train, True)
+        tag = "enc_train" if train else "enc_eval"
+        heads = {k: rel_l2(a[3][k].reshape(-1)[:64], b[3][k].reshape(-1)[:64]) for k in a[3]
+                 if not (train and is_pre_bn_bias(k)) and float(a[3][k].norm()) > 0}
+        out[tag + "_fused_rel_l2"] = rel_l2(a[1], b[1])
+        out[tag + "_gfeat_rel_l2"] = rel_l2(a[0], b[0])
+        out[tag + "_dx_rel_l2"] = rel_l2(a[2], b[2])
+        out[tag + "_grad_head_rel_l2_median"] = float(np.median(list(heads.values())))
+        out[tag + "_grad_head_rel_l2_worst"] = max(heads.values())
     sd = P.linerefine_state_dict(0)
     ctx, noisy, target = P.synth_batch(8, 256, 4, 32, seed=1234)
 
