@@ -153,6 +153,26 @@ int prh_linear_backward_bf16(const uint16_t* x, long ldx, const float* w, const 
                              float* db, int rows, int k, int n, void* workspace, size_t workspace_bytes, int device,
                              void* stream);
 
+/* ---- fused EVAL-mode encoder (src/model.py:39-62 with every BatchNorm in eval mode, + :147,194)
+ * One kernel takes context [B,N,C] to memory [B,N,256] = context_proj(fused) - and, optionally,
+ * fused [B,N,1024] and global_feat [B,2048] - with BatchNorm folded into the conv weights: a
+ * tile of points stays resident on the CU, the weights stream from L2, no activation touches
+ * HBM.  planes = 1: fp16 operands (BASELINE config 5, "batched fp16 forward"; parity gate 5e-2);
+ * planes = 2: two fp16 planes, three MFMA products, fp32-level error (parity gate 1e-4).
+ * Built for the reference's widths (64/128/256/512/1024, gate hidden 64, context_proj 256).
+ *   prepare: fold + split the weights ONCE per set of weights into `image`
+ *            (prh_encoder_fused_image_bytes bytes, 256-byte aligned); proj_w/proj_b [256,1024]/[256]
+ *            or NULL (encoder API only);
+ *   forward: any of memory / fused / gfeat may be NULL (at least one given); workspace
+ *            (prh_encoder_fused_workspace_bytes) is needed for gfeat only. */
+size_t prh_encoder_fused_image_bytes(int planes, int in_channel);
+int prh_encoder_fused_prepare(const prh_encoder_params* prm, float eps, const float* proj_w, const float* proj_b,
+                              int planes, void* image, size_t image_bytes, int device, void* stream);
+size_t prh_encoder_fused_workspace_bytes(int B, int N, int planes);
+int prh_encoder_fused_forward(const void* image, int planes, int in_channel, int has_proj, const float* ctx, int B,
+                              int N, float* memory, float* fused, float* gfeat, void* workspace,
+                              size_t workspace_bytes, int device, void* stream);
+
 /* nn.Linear forward y = act(x W^T + b): context_proj (src/model.py:147,194) and any
  * other Linear on the path.  x [rows,k] (ld ldx), w [n,k], y [rows,n]; relu: 0/1.
  * k and ldx must be multiples of 4.  workspace (may be NULL: exact fp32 MFMA core only) holds the

@@ -61,6 +61,8 @@ EXPORTS = [
     "prh_encoder_workspace_bytes", "prh_encoder_forward", "prh_encoder_backward",
     "prh_encoder_bf16_workspace_bytes", "prh_encoder_forward_bf16", "prh_encoder_backward_bf16",
     "prh_linear_bf16_workspace_bytes", "prh_linear_forward_bf16", "prh_linear_backward_bf16",
+    "prh_encoder_fused_image_bytes", "prh_encoder_fused_prepare", "prh_encoder_fused_workspace_bytes",
+    "prh_encoder_fused_forward",
     "prh_linear_forward_workspace_bytes", "prh_linear_forward", "prh_linear_forward_ex",
     "prh_linear_forward_full", "prh_operand_absmax_workspace_bytes", "prh_operand_absmax",
     "prh_linear_uses_operand_maxima", "prh_linear_backward_full", "prh_pos_hidden_forward", "prh_pos_hidden_backward_workspace_bytes",
@@ -131,6 +133,14 @@ def _bind(lib):
     lib.prh_linear_forward_bf16.argtypes = [vp, lg, vp, vp, vp, i, i, i, i, vp, sz, i, vp]
     lib.prh_linear_backward_bf16.restype = i
     lib.prh_linear_backward_bf16.argtypes = [vp, lg, vp, vp, vp, vp, vp, i, i, i, vp, sz, i, vp]
+    lib.prh_encoder_fused_image_bytes.restype = sz
+    lib.prh_encoder_fused_image_bytes.argtypes = [i, i]
+    lib.prh_encoder_fused_prepare.restype = i
+    lib.prh_encoder_fused_prepare.argtypes = [C.POINTER(EncoderParams), f, vp, vp, i, vp, sz, i, vp]
+    lib.prh_encoder_fused_workspace_bytes.restype = sz
+    lib.prh_encoder_fused_workspace_bytes.argtypes = [i, i, i]
+    lib.prh_encoder_fused_forward.restype = i
+    lib.prh_encoder_fused_forward.argtypes = [vp, i, i, i, vp, i, i, vp, vp, vp, vp, sz, i, vp]
     lib.prh_linear_forward.restype = i
     lib.prh_linear_forward.argtypes = [vp, lg, vp, vp, vp, i, i, i, i, vp, sz, i, vp]
     lib.prh_linear_forward_ex.restype = i

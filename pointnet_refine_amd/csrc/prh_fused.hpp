@@ -1,0 +1,421 @@
+// Fused EVAL-mode encoder: context (B,N,C) -> memory (B,N,256) [+ fused (B,N,1024), global_feat
+// (B,2048)] in ONE kernel (north_star "fused into a single CDNA4 kernel").
+// In eval mode BatchNorm is an affine map of running statistics, so it folds into the conv
+// weights and biases (src/model.py:43-55 with bn.eval()): no statistics, no cut between layers.
+//
+//   h_k = relu(W'_k h_{k-1} + b'_k), k = 1..5   W'_k = diag(s_k) W_k, b'_k = s_k (b_k - mean_k) + beta_k
+//   F   = relu(W'_f [h1..h5] + b'_f) * (0.5 + 0.5 sigmoid(W_g2 relu(i w_g1 + b_g1) + b_g2))
+//   memory = W_p F + b_p          global_feat = [max_n F | mean_n F]
+//
+// One 512-thread workgroup per tile of MT points of one segment; the tile's activations never
+// leave the CU: h1..h4 (960 channels) and a 256-channel chunk of h5 live in LDS as fp16 k-blocks
+// (32 channels x MT points, 64-B rows, the conflict-free chunk permutation of prh_gemm_h2.hpp),
+// 152 KB; the 1024-wide fusion accumulators live in registers (128 per lane) and take h5 chunk by
+// chunk, so the 1984-channel concat never exists anywhere.  Weights are the streamed operand:
+// every wave owns 1/8 of a layer's OUTPUT channels and reads its fragments of the prepared image
+// straight from L2 into registers (16 B per lane, 1 KB per fragment, register double buffer) -
+// no LDS, no barrier for weights; the activations are the shared operand, read from LDS.
+// Orientation D[channel][point] = W[channel][k] H[k][point] (A = weights, B = activations): a lane
+// then holds 4 consecutive channels of one point, i.e. 8 contiguous bytes of the next layer's
+// LDS image and 16 contiguous bytes of the fp32 outputs.
+//   NPL = 1: fp16 operands, MT = 64 (BASELINE config 5 "batched fp16 forward")
+//   NPL = 2: two fp16 planes per operand, three products (the split of prh_gemm_s3.hpp), MT = 32:
+//            fp32-level error, used for the 1e-4 parity path.  Weight planes carry a per-layer
+//            power-of-two scale; activations (post-BN, O(1)) are split unscaled, clamped to the
+//            fp16 range (absolute floor 2^-25).
+// HBM traffic per point: 4 C bytes in, 1 KB (memory) out - the rest is L2 weight streaming:
+// 6.1 MB (12.2 MB) of image per tile against 0.39 (0.20) GFLOP.
+#pragma once
+#include "prh_gemm_h2.hpp"
+
+namespace prh {
+
+constexpr int FE_NL = 7;                                   // conv2 conv3 conv4 conv5 fusion gate2 proj
+constexpr int FE_N[FE_NL] = {128, 256, 512, 1024, 1024, 1024, 256};
+constexpr int FE_K[FE_NL] = {64, 128, 256, 512, 1984, 64, 1024};
+constexpr int FE_LDS = 152 * 1024;
+
+struct FusedLayout {            // byte offsets into the prepared image
+  int planes, C;
+  size_t c1w, c1b, g1w, g1b;    // fp32: folded conv1 [64][C], [64]; gate hidden [64], [64]
+  size_t bias[FE_NL];           // fp32 [N]
+  size_t invs;                  // fp32 [8]: 1 / weight-plane scale per layer
+  size_t amax;                  // fp32 [8] (as uint bits during preparation)
+  size_t w[FE_NL];              // fragment images: [N/16][K/32][planes][64 lanes x 16 B]
+  size_t total;
+};
+inline FusedLayout fused_layout(int planes, int C) {
+  FusedLayout L; L.planes = planes; L.C = C;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o = (o + bytes + 255) / 256 * 256; return r; };
+  L.c1w = take((size_t)64 * C * 4); L.c1b = take(64 * 4); L.g1w = take(64 * 4); L.g1b = take(64 * 4);
+  for (int l = 0; l < FE_NL; ++l) L.bias[l] = take((size_t)FE_N[l] * 4);
+  L.invs = take(8 * 4); L.amax = take(8 * 4);
+  for (int l = 0; l < FE_NL; ++l) L.w[l] = take((size_t)FE_N[l] * FE_K[l] * 2 * planes);
+  L.total = o;
+  return L;
+}
+
+// ---- preparation (once per set of weights) ---------------------------------------------
+// folded bias b' = s (b - mean) + beta (BN layers) or b; s = gamma rsqrt(var + eps)
+__global__ void fe_bias_kernel(const float* b, const float* gamma, const float* beta, const float* rm,
+                               const float* rv, float eps, int N, float* out) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  if (gamma == nullptr) { out[n] = b != nullptr ? b[n] : 0.f; return; }
+  const float s = gamma[n] * rsqrtf(rv[n] + eps);
+  out[n] = s * ((b != nullptr ? b[n] : 0.f) - rm[n]) + beta[n];
+}
+// folded conv1 weight, fp32 [64][C] (the K = C layer runs on the VALU)
+__global__ void fe_conv1_kernel(const float* w, const float* gamma, const float* rv, float eps, int N, int C,
+                                float* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * C) return;
+  const int n = i / C;
+  out[i] = w[i] * gamma[n] * rsqrtf(rv[n] + eps);
+}
+// largest |s[n] W[n][k]| -> slot (uint bit pattern of a non-negative float orders like the float)
+__global__ __launch_bounds__(256) void fe_amax_kernel(const float* __restrict__ W, long ldw, int N, int K,
+                                                      const float* gamma, const float* rv, float eps, unsigned* slot) {
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)N * K; i += (long)gridDim.x * 256) {
+    const int n = (int)(i / K), k = (int)(i - (long)n * K);
+    const float s = gamma != nullptr ? gamma[n] * rsqrtf(rv[n] + eps) : 1.f;
+    m = fmaxf(m, fabsf(W[(size_t)n * ldw + k] * s));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(slot, __float_as_uint(m));
+}
+// fragment image: thread = (row block, k-step, lane); lane l holds W'[16 rb + (l & 15)][32 kt + 8 (l >> 4) + j]
+template <int NPL>
+__global__ __launch_bounds__(256) void fe_image_kernel(const float* __restrict__ W, long ldw, int N, int K,
+                                                       const float* gamma, const float* rv, float eps,
+                                                       const float* amax, float* invs_slot, char* __restrict__ out) {
+  const int KT = K / 32;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)(N / 16) * KT * 64) return;
+  const int lane = (int)(i & 63);
+  const int kt = (int)((i >> 6) % KT), rb = (int)((i >> 6) / KT);
+  const int n = rb * 16 + (lane & 15), k0 = kt * 32 + 8 * (lane >> 4);
+  const float S = NPL == 2 ? pow2_scale(*amax) : 1.f;
+  if (i == 0) *invs_slot = 1.f / S;
+  const float s = (gamma != nullptr ? gamma[n] * rsqrtf(rv[n] + eps) : 1.f) * S;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = W[(size_t)n * ldw + k0 + j] * s;
+  uint4 h, l;
+  split2h(v[0], v[1], h.x, l.x); split2h(v[2], v[3], h.y, l.y);
+  split2h(v[4], v[5], h.z, l.z); split2h(v[6], v[7], h.w, l.w);
+  char* q = out + (((size_t)rb * KT + kt) * NPL) * 1024 + lane * 16;
+  *reinterpret_cast<uint4*>(q) = h;
+  if (NPL == 2) *reinterpret_cast<uint4*>(q + 1024) = l;
+}
+
+// ---- the fused kernel --------------------------------------------------------------------
+struct FusedParams {
+  const float* ctx;           // [B, N, C]
+  const char* img;            // prepared image
+  FusedLayout L;
+  int B, N, tiles_per_seg;
+  float* memory;              // [B, N, 256] or null (no context_proj)
+  float* fused;               // [B, N, 1024] or null
+  float* pool_ws;             // [B * tiles_per_seg][2][1024] partial max / sum, or null
+};
+
+template <int NPL> struct FE {
+  static constexpr int MT = NPL == 1 ? 64 : 32;     // points per tile
+  static constexpr int CB = MT / 16;                // 16-point column blocks
+  static constexpr int PL = MT * 64;                // bytes of one plane of one k-block
+  static constexpr int KB = NPL * MT * 64;          // bytes of one k-block (32 channels): 4 KB either way
+};
+
+__device__ __forceinline__ uint2 fe_pack4(float a, float b, float c, float d) {
+  f32x2 v0 = {a, b}, v1 = {c, d};
+  f16x2 h0 = __builtin_convertvector(v0, f16x2), h1 = __builtin_convertvector(v1, f16x2);
+  return make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
+}
+// 4 values -> fp16 plane(s) at `p` (8 B per plane, planes PL apart); values clamped to the fp16 range
+template <int NPL>
+__device__ __forceinline__ void fe_put4(char* p, float a, float b, float c, float d) {
+  a = fminf(a, 65504.f); b = fminf(b, 65504.f); c = fminf(c, 65504.f); d = fminf(d, 65504.f);
+  if (NPL == 1) {
+    *reinterpret_cast<uint2*>(p) = fe_pack4(a, b, c, d);
+  } else {
+    uint2 h, l;
+    split2h(a, b, h.x, l.x);
+    split2h(c, d, h.y, l.y);
+    *reinterpret_cast<uint2*>(p) = h;
+    *reinterpret_cast<uint2*>(p + FE<NPL>::PL) = l;
+  }
+}
+
+// acc[R][CB] += W(this wave's R row blocks) H(lds k-blocks kb0 .. kb0 + nkb - 1); nkb even.
+// wimg: fragment (row block 0 of the wave, k-step 0, plane 0) + lane * 16; row blocks rbs bytes apart.
+template <int NPL, int R>
+__device__ __forceinline__ void fe_gemm(f32x4 (&acc)[R][FE<NPL>::CB], const char* lds, int kb0, int nkb,
+                                        const char* wimg, size_t rbs, int l15, int kc) {
+  constexpr int CB = FE<NPL>::CB;
+  f16x8 wf[2][R][NPL];
+  auto loadw = [&](f16x8 (&w)[R][NPL], int kt) {
+    kt = kt < nkb ? kt : nkb - 1;                      // tail: harmless re-read
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl)
+        w[r][pl] = *reinterpret_cast<const f16x8*>(wimg + r * rbs + ((size_t)kt * NPL + pl) * 1024);
+  };
+  auto step = [&](const f16x8 (&w)[R][NPL], int kt) {
+    const char* hb = lds + (size_t)(kb0 + kt) * FE<NPL>::KB;
+    f16x8 hf[CB][NPL];
+#pragma unroll
+    for (int c = 0; c < CB; ++c)
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl)
+        hf[c][pl] = *reinterpret_cast<const f16x8*>(hb + pl * FE<NPL>::PL + h2_off(c * 16 + l15, kc * 8));
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int c = 0; c < CB; ++c) {
+        if (NPL == 2) {
+          acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[r][NPL - 1], hf[c][0], acc[r][c], 0, 0, 0);
+          acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[r][0], hf[c][NPL - 1], acc[r][c], 0, 0, 0);
+        }
+        acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[r][0], hf[c][0], acc[r][c], 0, 0, 0);
+      }
+  };
+  // the scheduling barriers keep each k-step's fragment loads inside its own step: hoisted across
+  // steps (or across the unrolled calls of a caller) they pile up on top of the 128 accumulator
+  // registers and spill them
+  loadw(wf[0], 0);
+  for (int kt = 0; kt < nkb; kt += 2) {
+    loadw(wf[1], kt + 1);
+    step(wf[0], kt);
+    __builtin_amdgcn_sched_barrier(0);
+    loadw(wf[0], kt + 2);
+    step(wf[1], kt + 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// v = relu(acc * invs + bias) -> fp16 planes in LDS: channel n of this layer at k-block
+// kb_base + (n >> 5), row = point, column n & 31.  ch0: the wave's first channel.
+template <int NPL, int R, bool RELU>
+__device__ __forceinline__ void fe_store_act(const f32x4 (&acc)[R][FE<NPL>::CB], char* lds, int kb_base, int ch0,
+                                             const float* bias, float invs, int l15, int q) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int n = ch0 + r * 16 + 4 * q;
+    float4 b = bias != nullptr ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int c = 0; c < FE<NPL>::CB; ++c) {
+      float v0 = fmaf(acc[r][c][0], invs, b.x), v1 = fmaf(acc[r][c][1], invs, b.y);
+      float v2 = fmaf(acc[r][c][2], invs, b.z), v3 = fmaf(acc[r][c][3], invs, b.w);
+      if (RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+      fe_put4<NPL>(lds + (size_t)(kb_base + (n >> 5)) * FE<NPL>::KB + h2_off(c * 16 + l15, n & 31), v0, v1, v2, v3);
+    }
+  }
+}
+
+template <int R, int CB>
+__device__ __forceinline__ void fe_zero(f32x4 (&acc)[R][CB]) {
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int c = 0; c < CB; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[r][c][e] = 0.f;
+}
+
+template <int NPL>
+__global__ __launch_bounds__(512, 2) void encoder_fused_kernel(const FusedParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using T = FE<NPL>;
+  constexpr int MT = T::MT, CB = T::CB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, q = lane >> 4;
+  const int seg = blockIdx.x / p.tiles_per_seg, tile = blockIdx.x - seg * p.tiles_per_seg;
+  const int n0 = tile * MT;
+  int valid = p.N - n0; valid = valid > MT ? MT : valid;
+  const size_t row0 = (size_t)seg * p.N + n0;
+  const int C = p.L.C;
+  const char* img = p.img;
+  const float* invs = reinterpret_cast<const float*>(img + p.L.invs);
+  auto wptr = [&](int layer, int R) {     // this wave's first fragment of a layer
+    return img + p.L.w[layer] + (size_t)(wave * R) * (FE_K[layer] / 32) * NPL * 1024 + lane * 16;
+  };
+  auto rbs = [&](int layer) { return (size_t)(FE_K[layer] / 32) * NPL * 1024; };
+  auto biasp = [&](int layer) { return reinterpret_cast<const float*>(img + p.L.bias[layer]); };
+  // LDS k-block map: h1 0..1, h2 2..5, h3 6..13, h4 14..29, h5 chunk 30..37
+  constexpr int KB_H1 = 0, KB_H2 = 2, KB_H3 = 6, KB_H4 = 14, KB_H5 = 30;
+
+  // ---- conv1 + bn1 + relu on the VALU (K = C): item = (point, group of 8 channels)
+  {
+    const float* w1 = reinterpret_cast<const float*>(img + p.L.c1w);
+    const float* b1 = reinterpret_cast<const float*>(img + p.L.c1b);
+    for (int it = tid; it < MT * 8; it += 512) {
+      const int pt = it % MT, g = it / MT;
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = b1[g * 8 + j];
+      if (pt < valid) {
+        const float* x = p.ctx + (row0 + pt) * C;
+        for (int c = 0; c < C; ++c) {
+          const float xv = x[c];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = fmaf(w1[(g * 8 + j) * C + c], xv, o[j]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = fmaxf(o[j], 0.f);
+      char* d = smem + (size_t)(KB_H1 + (g >> 2)) * T::KB + h2_off(pt, (g & 3) * 8);
+      fe_put4<NPL>(d, o[0], o[1], o[2], o[3]);
+      fe_put4<NPL>(d + 8, o[4], o[5], o[6], o[7]);
+    }
+  }
+  __syncthreads();
+  // ---- conv2..4: every wave computes 1/8 of the output channels for all MT points
+  {
+    f32x4 a2[1][CB]; fe_zero(a2);
+    fe_gemm<NPL, 1>(a2, smem, KB_H1, 2, wptr(0, 1), rbs(0), l15, q);
+    fe_store_act<NPL, 1, true>(a2, smem, KB_H2, wave * 16, biasp(0), invs[0], l15, q);
+  }
+  __syncthreads();
+  {
+    f32x4 a3[2][CB]; fe_zero(a3);
+    fe_gemm<NPL, 2>(a3, smem, KB_H2, 4, wptr(1, 2), rbs(1), l15, q);
+    fe_store_act<NPL, 2, true>(a3, smem, KB_H3, wave * 32, biasp(1), invs[1], l15, q);
+  }
+  __syncthreads();
+  {
+    f32x4 a4[4][CB]; fe_zero(a4);
+    fe_gemm<NPL, 4>(a4, smem, KB_H3, 8, wptr(2, 4), rbs(2), l15, q);
+    fe_store_act<NPL, 4, true>(a4, smem, KB_H4, wave * 64, biasp(2), invs[2], l15, q);
+  }
+  __syncthreads();
+  // ---- fusion conv, K range of h1..h4 (960 channels = k-blocks 0..29, in concat order)
+  // (two passes of 4 row blocks each: the weight double buffer of an 8-block pass, 64 registers,
+  // does not fit next to the 128 accumulator registers; the activation fragments are re-read)
+  f32x4 F[2][4][CB];
+  fe_zero(F[0]); fe_zero(F[1]);
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf)
+    fe_gemm<NPL, 4>(F[hf], smem, 0, 30, wptr(4, 8) + (size_t)hf * 4 * rbs(4), rbs(4), l15, q);
+  // ---- conv5 in four 256-channel chunks, each consumed by the fusion conv at once
+  for (int ch = 0; ch < 4; ++ch) {
+    f32x4 a5[2][CB]; fe_zero(a5);
+    // chunk ch = row blocks 16 ch .. 16 ch + 15 of conv5; this wave: 2 of them
+    const char* w5 = img + p.L.w[3] + (size_t)(ch * 16 + wave * 2) * (FE_K[3] / 32) * NPL * 1024 + lane * 16;
+    fe_gemm<NPL, 2>(a5, smem, KB_H4, 16, w5, rbs(3), l15, q);
+    if (ch > 0) __syncthreads();                // the previous chunk's fusion reads are done
+    fe_store_act<NPL, 2, true>(a5, smem, KB_H5, wave * 32, biasp(3) + ch * 256, invs[3], l15, q);
+    __syncthreads();
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+      fe_gemm<NPL, 4>(F[hf], smem, KB_H5, 8, wptr(4, 8) + (size_t)hf * 4 * rbs(4) + (size_t)(30 + ch * 8) * NPL * 1024,
+                      rbs(4), l15, q);
+  }
+  __syncthreads();
+  // ---- gate hidden layer u = relu(i w1 + b1) into k-blocks 0..1 (h1 is dead)
+  {
+    const float* gw = reinterpret_cast<const float*>(img + p.L.g1w);
+    const float* gb = reinterpret_cast<const float*>(img + p.L.g1b);
+    for (int it = tid; it < MT * 8; it += 512) {
+      const int pt = it % MT, g = it / MT;
+      const float iv = pt < valid ? p.ctx[(row0 + pt) * C + 3] : 0.f;
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = fmaxf(fmaf(iv, gw[g * 8 + j], gb[g * 8 + j]), 0.f);
+      char* d = smem + (size_t)(g >> 2) * T::KB + h2_off(pt, (g & 3) * 8);
+      fe_put4<NPL>(d, o[0], o[1], o[2], o[3]);
+      fe_put4<NPL>(d + 8, o[4], o[5], o[6], o[7]);
+    }
+  }
+  __syncthreads();
+  // ---- gate GEMM (K = 64) row block by row block, combine, pooling partials, optional store
+  {
+    const float* bf = biasp(4) + wave * 128;
+    const float* bg = biasp(5) + wave * 128;
+    const float sf = invs[4], sg = invs[5];
+    const char* wg = wptr(5, 8);
+    float* pw = p.pool_ws != nullptr ? p.pool_ws + (size_t)blockIdx.x * 2048 + wave * 128 : nullptr;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      f32x4 g1[1][CB]; fe_zero(g1);
+      fe_gemm<NPL, 1>(g1, smem, 0, 2, wg + (size_t)r * rbs(5), rbs(5), l15, q);
+      const int n = r * 16 + 4 * q;
+      const float4 b4 = *reinterpret_cast<const float4*>(bf + n), c4 = *reinterpret_cast<const float4*>(bg + n);
+      const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, cc[4] = {c4.x, c4.y, c4.z, c4.w};
+      float mx[4] = {0.f, 0.f, 0.f, 0.f}, sm[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < CB; ++c) {
+        const bool ok = c * 16 + l15 < valid;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float f = fmaxf(fmaf(F[r >> 2][r & 3][c][e], sf, bb[e]), 0.f);
+          const float m = 0.5f + 0.5f / (1.f + __expf(-fmaf(g1[0][c][e], sg, cc[e])));
+          const float v = f * m;
+          F[r >> 2][r & 3][c][e] = v;
+          mx[e] = fmaxf(mx[e], ok ? v : 0.f);     // F >= 0: 0 is neutral for the max
+          sm[e] += ok ? v : 0.f;
+        }
+        if (p.fused != nullptr && ok)
+          *reinterpret_cast<float4*>(p.fused + (row0 + c * 16 + l15) * 1024 + wave * 128 + n) =
+              make_float4(F[r >> 2][r & 3][c][0], F[r >> 2][r & 3][c][1], F[r >> 2][r & 3][c][2], F[r >> 2][r & 3][c][3]);
+      }
+      if (pw != nullptr) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) {
+            mx[e] = fmaxf(mx[e], __shfl_xor(mx[e], o));
+            sm[e] += __shfl_xor(sm[e], o);
+          }
+        if (l15 == 0) {
+          *reinterpret_cast<float4*>(pw + n) = make_float4(mx[0], mx[1], mx[2], mx[3]);
+          *reinterpret_cast<float4*>(pw + 1024 + n) = make_float4(sm[0], sm[1], sm[2], sm[3]);
+        }
+      }
+    }
+  }
+  if (p.memory == nullptr) return;
+  __syncthreads();                               // u is dead
+  // ---- context_proj: F -> fp16 planes (k-blocks 0..31), memory = W_p F + b_p
+  fe_store_act<NPL, 4, false>(F[0], smem, 0, wave * 128, nullptr, 1.f, l15, q);
+  fe_store_act<NPL, 4, false>(F[1], smem, 0, wave * 128 + 64, nullptr, 1.f, l15, q);
+  __syncthreads();
+  {
+    f32x4 am[2][CB]; fe_zero(am);
+    fe_gemm<NPL, 2>(am, smem, 0, 32, wptr(6, 2), rbs(6), l15, q);
+    const float sp = invs[6];
+    const float* bp = biasp(6) + wave * 32;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int n = r * 16 + 4 * q;
+      const float4 b4 = *reinterpret_cast<const float4*>(bp + n);
+#pragma unroll
+      for (int c = 0; c < CB; ++c)
+        if (c * 16 + l15 < valid)
+          *reinterpret_cast<float4*>(p.memory + (row0 + c * 16 + l15) * 256 + wave * 32 + n) =
+              make_float4(fmaf(am[r][c][0], sp, b4.x), fmaf(am[r][c][1], sp, b4.y), fmaf(am[r][c][2], sp, b4.z),
+                          fmaf(am[r][c][3], sp, b4.w));
+    }
+  }
+}
+
+// global_feat = [max over the segment's tiles | sum / N]
+__global__ __launch_bounds__(256) void fe_pool_final_kernel(const float* __restrict__ ws, int tiles_per_seg, int N,
+                                                            float* __restrict__ gfeat) {
+  const int b = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= 1024) return;
+  float mx = 0.f, sm = 0.f;
+  for (int t = 0; t < tiles_per_seg; ++t) {
+    const float* w = ws + ((size_t)b * tiles_per_seg + t) * 2048;
+    mx = fmaxf(mx, w[n]);
+    sm += w[1024 + n];
+  }
+  gfeat[(size_t)b * 2048 + n] = mx;
+  gfeat[(size_t)b * 2048 + 1024 + n] = sm / (float)N;
+}
+
+}  // namespace prh

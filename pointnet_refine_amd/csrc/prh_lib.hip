@@ -19,6 +19,7 @@
 #include "prh_gemm_s3.hpp"
 #include "prh_gemm_h2.hpp"
 #include "prh_b16.hpp"
+#include "prh_fused.hpp"
 #include "prh_context.hpp"
 #include "prh_kernels.hpp"
 
@@ -1735,6 +1736,121 @@ int prh_linear_backward_bf16(const uint16_t* x, long ldx, const float* w, const 
     TNParams t; memset(&t, 0, sizeof(t));
     t.A = f16p(lw.dy16); t.lda = n; t.B = f16p(x); t.ldb = ldx; t.P = rows; t.Mo = n; t.Ni = k;
     TRY((launch_tn_b16<PRO_NONE>(t, lw.slab, lw.cslab, dw, (long)k, db, st)));
+  }
+  return PRH_OK;
+}
+
+// ------------------------------------------------------------------ fused eval encoder (prh_fused.hpp)
+size_t prh_encoder_fused_image_bytes(int planes, int in_channel) {
+  if ((planes != 1 && planes != 2) || in_channel < 4 || in_channel > 64) return 0;
+  return fused_layout(planes, in_channel).total + 256;
+}
+int prh_encoder_fused_prepare(const prh_encoder_params* prm, float eps, const float* proj_w, const float* proj_b,
+                              int planes, void* image, size_t image_bytes, int device, void* stream) {
+  TRY(check_encoder(prm));
+  if (planes != 1 && planes != 2) return fail(PRH_ERR_ARG, "encoder_fused_prepare: planes must be 1 (fp16) or 2 (split fp16)");
+  if (prm->in_channel > 64) return fail(PRH_ERR_ARG, "encoder_fused_prepare: at most 64 input channels");
+  static const int want[5] = {64, 128, 256, 512, 1024};
+  for (int l = 0; l < 5; ++l)
+    if (prm->conv[l].cout != want[l])
+      return fail(PRH_ERR_ARG, "encoder_fused_prepare: the fused kernel is built for widths 64/128/256/512/1024 (conv%d has %d)",
+                  l + 1, prm->conv[l].cout);
+  if (prm->out_dim != 1024) return fail(PRH_ERR_ARG, "encoder_fused_prepare: out_dim must be 1024");
+  if (!image || ((uintptr_t)image & 255)) return fail(PRH_ERR_ARG, "encoder_fused_prepare: image must be 256-byte aligned");
+  const FusedLayout L = fused_layout(planes, prm->in_channel);
+  if (image_bytes < L.total) return fail(PRH_ERR_WORKSPACE, "encoder_fused_prepare: image buffer too small (%zu < %zu)", image_bytes, L.total);
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  char* img = (char*)image;
+  const int C = prm->in_channel;
+  auto f32 = [&](size_t off) { return reinterpret_cast<float*>(img + off); };
+  HIP_TRY(hipMemsetAsync(img + L.amax, 0, 32, st));
+  // conv1 (VALU layer) and the gate's hidden layer: fp32
+  hipLaunchKernelGGL(fe_conv1_kernel, dim3(cdiv(64 * C, 256)), dim3(256), 0, st, prm->conv[0].w, prm->conv[0].gamma,
+                     (const float*)prm->conv[0].running_var, eps, 64, C, f32(L.c1w));
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(fe_bias_kernel, dim3(1), dim3(64), 0, st, prm->conv[0].b, prm->conv[0].gamma, prm->conv[0].beta,
+                     (const float*)prm->conv[0].running_mean, (const float*)prm->conv[0].running_var, eps, 64, f32(L.c1b));
+  LAUNCH_CHECK();
+  HIP_TRY(hipMemcpyAsync(f32(L.g1w), prm->gate_w1, 64 * 4, hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemcpyAsync(f32(L.g1b), prm->gate_b1, 64 * 4, hipMemcpyDeviceToDevice, st));
+  struct Src { const float* w; const float* b; const float* gamma; const float* beta; const float* rm; const float* rv; };
+  Src src[FE_NL];
+  for (int l = 0; l < 4; ++l) {
+    const prh_bn_layer& y = prm->conv[l + 1];
+    src[l] = {y.w, y.b, y.gamma, y.beta, y.running_mean, y.running_var};
+  }
+  src[4] = {prm->fusion.w, prm->fusion.b, prm->fusion.gamma, prm->fusion.beta, prm->fusion.running_mean, prm->fusion.running_var};
+  src[5] = {prm->gate_w2, prm->gate_b2, nullptr, nullptr, nullptr, nullptr};
+  src[6] = {proj_w, proj_b, nullptr, nullptr, nullptr, nullptr};
+  for (int l = 0; l < FE_NL; ++l) {
+    if (src[l].w == nullptr) continue;                      // no context_proj: image slot left unused
+    const int N = FE_N[l], K = FE_K[l];
+    hipLaunchKernelGGL(fe_bias_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, src[l].b, src[l].gamma, src[l].beta, src[l].rm,
+                       src[l].rv, eps, N, f32(L.bias[l]));
+    LAUNCH_CHECK();
+    float* amax = f32(L.amax) + l;
+    if (planes == 2) {
+      hipLaunchKernelGGL(fe_amax_kernel, dim3(256), dim3(256), 0, st, src[l].w, (long)K, N, K, src[l].gamma, src[l].rv, eps,
+                         reinterpret_cast<unsigned*>(amax));
+      LAUNCH_CHECK();
+    }
+    const long th = (long)(N / 16) * (K / 32) * 64;
+    if (planes == 2)
+      hipLaunchKernelGGL(fe_image_kernel<2>, dim3((unsigned)cdiv(th, 256)), dim3(256), 0, st, src[l].w, (long)K, N, K,
+                         src[l].gamma, src[l].rv, eps, (const float*)amax, f32(L.invs) + l, img + L.w[l]);
+    else
+      hipLaunchKernelGGL(fe_image_kernel<1>, dim3((unsigned)cdiv(th, 256)), dim3(256), 0, st, src[l].w, (long)K, N, K,
+                         src[l].gamma, src[l].rv, eps, (const float*)amax, f32(L.invs) + l, img + L.w[l]);
+    LAUNCH_CHECK();
+  }
+  return PRH_OK;
+}
+size_t prh_encoder_fused_workspace_bytes(int B, int N, int planes) {
+  if (B <= 0 || N <= 0 || (planes != 1 && planes != 2)) return 0;
+  const int mt = planes == 1 ? 64 : 32;
+  return (size_t)B * cdiv(N, mt) * 2048 * sizeof(float) + 256;
+}
+int prh_encoder_fused_forward(const void* image, int planes, int in_channel, int has_proj, const float* ctx, int B,
+                              int N, float* memory, float* fused, float* gfeat, void* workspace,
+                              size_t workspace_bytes, int device, void* stream) {
+  if (!image || !ctx || B <= 0 || N <= 0 || (planes != 1 && planes != 2) || in_channel < 4 || in_channel > 64)
+    return fail(PRH_ERR_ARG, "encoder_fused_forward: bad argument");
+  if (memory != nullptr && !has_proj) return fail(PRH_ERR_ARG, "encoder_fused_forward: memory wanted but the image has no context_proj");
+  if (!memory && !fused && !gfeat) return fail(PRH_ERR_ARG, "encoder_fused_forward: no output requested");
+  if ((long)B * N > 2000000000L) return fail(PRH_ERR_ARG, "encoder_fused_forward: B*N too large");
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  FusedParams p; memset(&p, 0, sizeof(p));
+  p.L = fused_layout(planes, in_channel);
+  p.ctx = ctx; p.img = (const char*)image; p.B = B; p.N = N;
+  const int mt = planes == 1 ? 64 : 32;
+  p.tiles_per_seg = cdiv(N, mt);
+  p.memory = memory; p.fused = fused;
+  if (gfeat != nullptr) {
+    Arena a(workspace, workspace_bytes);
+    p.pool_ws = a.f((size_t)B * p.tiles_per_seg * 2048);
+    if (!a.ok) return fail(PRH_ERR_WORKSPACE, "encoder_fused_forward: workspace too small (%zu bytes)", workspace_bytes);
+  }
+  const unsigned grid = (unsigned)((long)B * p.tiles_per_seg);
+  {
+    const double P = (double)B * N;
+    ProfScope ps(planes == 1 ? "encoder_fused<1>" : "encoder_fused<2>", 2.0 * P * (2793792.0 + (memory ? 262144.0 : 0.0)),
+                 P * (4.0 * in_channel + (memory ? 1024.0 : 0.0) + (fused ? 4096.0 : 0.0)), st);
+    if (planes == 1) {
+      static const int attr = allow_big_lds(encoder_fused_kernel<1>);
+      if (attr != PRH_OK) return attr;
+      hipLaunchKernelGGL(encoder_fused_kernel<1>, dim3(grid), dim3(512), FE_LDS, st, p);
+    } else {
+      static const int attr = allow_big_lds(encoder_fused_kernel<2>);
+      if (attr != PRH_OK) return attr;
+      hipLaunchKernelGGL(encoder_fused_kernel<2>, dim3(grid), dim3(512), FE_LDS, st, p);
+    }
+    LAUNCH_CHECK();
+  }
+  if (gfeat != nullptr) {
+    hipLaunchKernelGGL(fe_pool_final_kernel, dim3(4, B), dim3(256), 0, st, (const float*)p.pool_ws, p.tiles_per_seg, N, gfeat);
+    LAUNCH_CHECK();
   }
   return PRH_OK;
 }

@@ -102,6 +102,15 @@ class MultiScalePointNetEncoder(nn.Module):
                                             nn.Conv1d(self.GATE_HIDDEN, out_dim, kernel_size=1),
                                             nn.Sigmoid())
         self.in_channel, self.out_dim = in_channel, out_dim
+        # inference (eval mode under torch.no_grad()): "fp32" / "fp16" = the single fused kernel with
+        # BatchNorm folded (two fp16 planes, fp32-level error / one fp16 plane, BASELINE config 5);
+        # None = the per-layer kernels that also serve training
+        self.inference_precision = "fp32"
+
+    def _fused_ok(self, x):
+        return (self.inference_precision in ("fp32", "fp16") and not self.training and not torch.is_grad_enabled()
+                and x.is_cuda and x.dtype == torch.float32 and self.out_dim == 1024
+                and ops.encoder_eval_fused_supported(self._param_list()))
 
     def _param_list(self):
         sd = dict(self.named_parameters())
@@ -120,6 +129,11 @@ class MultiScalePointNetEncoder(nn.Module):
         if x_pm.dim() != 3:
             raise RuntimeError(f"Expected 3D (batched) input, but got input of size: {list(x_pm.shape)}")
         bn = self.bn1
+        if self._fused_ok(x_pm):
+            _, fused, gfeat = ops.encoder_eval_fused(x_pm, self._param_list(), self._bn_buffer_list(), bn.eps,
+                                                     want_fused=True, want_global=want_global,
+                                                     precision=self.inference_precision)
+            return gfeat, fused
         return ops.encoder(x_pm, self._param_list(), self._bn_buffer_list(), want_global, self.training,
                            bn.momentum, bn.eps)
 
@@ -253,6 +267,12 @@ class LineRefineNet(nn.Module):
         enc = self.context_encoder
         if context.dim() != 3:
             raise RuntimeError(f"Expected 3D (batched) input, but got input of size: {list(context.shape)}")
+        if enc._fused_ok(context) and tuple(self.context_proj.weight.shape) == (256, 1024):
+            # inference: encoder + context_proj as ONE kernel, no activation leaves the chip
+            memory, _, _ = ops.encoder_eval_fused(context, enc._param_list(), enc._bn_buffer_list(), enc.bn1.eps,
+                                                  self.context_proj.weight, self.context_proj.bias,
+                                                  precision=enc.inference_precision)
+            return memory
         _, fused, fused_amax = ops.encoder_with_amax(context, enc._param_list(), enc._bn_buffer_list(), False,
                                                      enc.training, enc.bn1.momentum, enc.bn1.eps)
         return ops.linear(fused, self.context_proj.weight, self.context_proj.bias, fused_amax)

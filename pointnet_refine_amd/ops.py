@@ -447,6 +447,8 @@ class EncoderFn(torch.autograd.Function):
                                f"[{B}, {Cin}, {N}] to have {p2[0].shape[1]} channels, but got {Cin} channels instead")
         if training and B * N < 2:
             raise ValueError(f"Expected more than 1 value per channel when training, got input size {(B, Cin, N)}")
+        if training:
+            invalidate_fused_images()          # the running statistics are about to change
         out_dim = p2[8].shape[0]
         cat = 64 + 128 + 256 + 512 + out_dim
         P = B * N
@@ -603,6 +605,85 @@ def encoder_with_amax(x_pm, params, buffers, want_global, training, momentum, ep
     gfeat, fused = EncoderFn.apply(x_pm, want_global, training, momentum, eps, list(buffers), *params)
     amax, EncoderFn.last_fused_amax = EncoderFn.last_fused_amax, None
     return gfeat, fused, amax
+
+
+# ------------------------------------------------------------------------------------------
+# Fused eval-mode encoder (+ context_proj): one kernel, BatchNorm folded (csrc/prh_fused.hpp)
+# ------------------------------------------------------------------------------------------
+_FUSED_IMAGES = {}
+
+
+def invalidate_fused_images():
+    """Drop the cached weight images of encoder_eval_fused.  The cache is keyed on the tensors'
+    version counters; kernels of this library that write parameters or BatchNorm buffers through
+    raw pointers (the fused Adam step, the training forward's running statistics) call this."""
+    _FUSED_IMAGES.clear()
+
+
+def _tensor_key(t):
+    return (t.data_ptr(), t._version, tuple(t.shape))
+
+
+def encoder_eval_fused_supported(params, proj_w=None):
+    """The fused kernel is built for the reference's widths (src/model.py:10-37,147)."""
+    widths = [params[2 * k].shape[0] for k in range(5)]
+    ok = widths == [64, 128, 256, 512, 1024] and params[20].shape[0] == 1024 and params[24].shape[0] == 64
+    ok = ok and 4 <= params[0].shape[1] <= 64
+    if proj_w is not None:
+        ok = ok and tuple(proj_w.shape) == (256, 1024)
+    return ok
+
+
+def encoder_eval_fused(x_pm, params, buffers, eps, proj_w=None, proj_b=None, want_fused=False, want_global=False,
+                       precision="fp32"):
+    """Eval-mode MultiScalePointNetEncoder (+ context_proj) in ONE kernel with BatchNorm folded into
+    the weights (src/model.py:39-62 in eval mode, :194): x (B,N,C) -> (memory (B,N,256) or None,
+    fused (B,N,1024) or None, global_feat (B,2048) or None).  precision "fp32": two fp16 planes,
+    three products, fp32-level error; "fp16": one fp16 plane (BASELINE config 5).  Inference only
+    (no autograd).  The folded / split weight image is prepared once per set of weights and cached
+    (keyed on the tensors' addresses and version counters)."""
+    _req_gpu_f32(x_pm, "input")
+    if precision not in ("fp32", "fp16"):
+        raise ValueError("encoder_eval_fused: precision must be 'fp32' or 'fp16'")
+    planes = 2 if precision == "fp32" else 1
+    dev = x_pm.device
+    x = x_pm.contiguous()
+    B, N, Cin = x.shape
+    p2 = list(params)
+    for i in (0, 2, 4, 6, 8, 20, 24, 26):    # Conv1d weights (cout,cin,1) -> (cout,cin)
+        p2[i] = params[i].reshape(params[i].shape[0], -1)
+    if Cin != p2[0].shape[1]:
+        raise RuntimeError(f"Given groups=1, weight of size {list(params[0].shape)}, expected input"
+                           f"[{B}, {Cin}, {N}] to have {p2[0].shape[1]} channels, but got {Cin} channels instead")
+    if not encoder_eval_fused_supported(p2, proj_w):
+        raise RuntimeError("encoder_eval_fused: built for widths 64/128/256/512/1024, gate hidden 64, context_proj 256x1024")
+    lib = L.lib()
+    key = (dev.index, planes, float(eps), tuple(_tensor_key(t) for t in params),
+           tuple(_tensor_key(t) for t in buffers if t.is_floating_point()),
+           None if proj_w is None else (_tensor_key(proj_w), None if proj_b is None else _tensor_key(proj_b)))
+    slot = (dev.index, planes, id(params[0]), proj_w is not None)
+    ent = _FUSED_IMAGES.get(slot)
+    if ent is None or ent[0] != key:
+        p3 = [t.contiguous() for t in p2]
+        prm = _enc_params_struct(p3, buffers, Cin)
+        nb = lib.prh_encoder_fused_image_bytes(planes, Cin)
+        img = torch.empty(nb + 256, dtype=torch.uint8, device=dev)
+        off = (-img.data_ptr()) % 256
+        pw = proj_w.contiguous() if proj_w is not None else None
+        L.check(lib.prh_encoder_fused_prepare(C.byref(prm), float(eps), _p(pw), _p(proj_b), planes,
+                                              C.c_void_p(img.data_ptr() + off), nb, dev.index, _stream(dev)),
+                "prh_encoder_fused_prepare")
+        ent = (key, img, off)
+        _FUSED_IMAGES[slot] = ent
+    _, img, off = ent
+    memory = torch.empty((B, N, 256), dtype=torch.float32, device=dev) if proj_w is not None else None
+    fused = torch.empty((B, N, 1024), dtype=torch.float32, device=dev) if want_fused else None
+    gfeat = torch.empty((B, 2048), dtype=torch.float32, device=dev) if want_global else None
+    ws = _ws(dev, lib.prh_encoder_fused_workspace_bytes(B, N, planes)) if want_global else None
+    L.check(lib.prh_encoder_fused_forward(C.c_void_p(img.data_ptr() + off), planes, Cin, int(proj_w is not None), _p(x),
+                                          B, N, _p(memory), _p(fused), _p(gfeat), _p(ws), ws.numel() if ws is not None else 0,
+                                          dev.index, _stream(dev)), "prh_encoder_fused_forward")
+    return memory, fused, gfeat
 
 
 # ------------------------------------------------------------------------------------------

@@ -125,6 +125,8 @@ class FlatAdam:
         import ctypes as C
         from . import _lib as L
         self.steps += 1
+        from . import ops
+        ops.invalidate_fused_images()          # this kernel writes the weights behind autograd's version counters
         g = self.param_groups[0]
         dev = self.flat.device
         p = lambda t: C.c_void_p(t.data_ptr())
