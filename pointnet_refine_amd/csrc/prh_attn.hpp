@@ -92,14 +92,16 @@ __device__ __forceinline__ void tile_store(float* tile, int lane, const float (&
 }
 
 // ---------------------------------------------------------------------------------------
-// forward: block = 4 waves = 4 heads of one segment; grid = B * H/4
+// forward: block = WPB waves = WPB heads of one segment (WPB = blockDim.x / 64: 4 normally, 1 for
+// small batches, where B * H / 4 workgroups would leave most of the 256 CUs idle); grid = B * H / WPB
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) float smem[4 * AT_TILE];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h2 = lane >> 5, l31 = lane & 31;
-  const int hpb = p.H / 4;                          // blocks per segment
-  const int b = blockIdx.x / hpb, h = (blockIdx.x % hpb) * 4 + wave;
+  const int wpb = blockDim.x >> 6;
+  const int hpb = p.H / wpb;                        // blocks per segment
+  const int b = blockIdx.x / hpb, h = (blockIdx.x % hpb) * wpb + wave;
   const unsigned seed_eff = effective_seed(p.seed, p.seed_src);
   float* vt = smem + wave * AT_TILE;                // this wave's V tile
   const int col0 = h * 32;
@@ -186,8 +188,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h2 = lane >> 5, l31 = lane & 31;
-  const int hpb = p.H / 4;
-  const int b = blockIdx.x / hpb, h = (blockIdx.x % hpb) * 4 + wave;
+  const int wpb = blockDim.x >> 6;
+  const int hpb = p.H / wpb;
+  const int b = blockIdx.x / hpb, h = (blockIdx.x % hpb) * wpb + wave;
   const unsigned seed_eff = effective_seed(p.seed, p.seed_src);
   float* qtile = dsm + wave * (4 * AT_TILE);
   float* dotile = qtile + AT_TILE;
@@ -331,8 +334,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnParams p) {
       mx_dk = fmaxf(mx_dk, __shfl_xor(mx_dk, o));
     }
     if (lane == 0) {
-      p.kv_amax_part[(size_t)(blockIdx.x * 4 + wave) * 2] = mx_dv;
-      p.kv_amax_part[(size_t)(blockIdx.x * 4 + wave) * 2 + 1] = mx_dk;
+      p.kv_amax_part[(size_t)(blockIdx.x * wpb + wave) * 2] = mx_dv;
+      p.kv_amax_part[(size_t)(blockIdx.x * wpb + wave) * 2 + 1] = mx_dk;
     }
   }
 }

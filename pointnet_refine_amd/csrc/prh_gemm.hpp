@@ -41,6 +41,10 @@ enum {
   F_STORE_GATE = 16,  // EPI_GATE: also store m = 0.5+0.5*sigmoid() to C2
   F_E1_ROWVEC = 32,   // EPI_DGRAD: E1 is one value per row (E1[row*lde1]), not a matrix
   F_RESID = 64,       // EPI_BIAS: C = acc + bias + E1 (residual input, before the optional ReLU)
+  F_POOL = 128,       // EPI_GATE (vector epilogue): per 128-row wave tile and column, the largest output,
+                      //   the tile-local row of its FIRST occurrence and the column sum -> ws_a / ws_c (int
+                      //   bits) / ws_b [2*row_tiles][N]: the dual pooling (src/model.py:58-60) rides on the
+                      //   epilogue that produces `fused`; pool_tiles_kernel combines the tiles of a segment
 };
 
 struct NTParams {
@@ -430,6 +434,9 @@ __device__ __forceinline__ void nt_epilogue_vec(ACC& acc, const NTParams& p, int
   const bool resid = EPI == EPI_BIAS && (p.flags & F_RESID) != 0;
   const bool need_z = (EPI == EPI_DGRAD && (mask || (p.flags & F_STATS) != 0)) || EPI == EPI_GATE || resid;
   float4 s1 = zero4(), s2 = zero4();
+  const bool pool = EPI == EPI_GATE && (p.flags & F_POOL) != 0;
+  float pmx[4] = {-1.f, -1.f, -1.f, -1.f}, psm[4] = {0.f, 0.f, 0.f, 0.f};     // outputs are >= 0
+  int pix[4] = {0, 0, 0, 0};
   // The epilogue operands (z for the ReLU mask / statistics / gate, the old C when
   // accumulating) are fetched in ONE batch per 32-row block, branch-free (rows and columns
   // clamped into the tile's valid range; only the store is predicated), so a block exposes a
@@ -518,6 +525,15 @@ __device__ __forceinline__ void nt_epilogue_vec(ACC& acc, const NTParams& p, int
         v.x = fmaxf(fmaf(z.x, es4.x, et4.x), 0.f) * m.x; v.y = fmaxf(fmaf(z.y, es4.y, et4.y), 0.f) * m.y;
         v.z = fmaxf(fmaf(z.z, es4.z, et4.z), 0.f) * m.z; v.w = fmaxf(fmaf(z.w, es4.w, et4.w), 0.f) * m.w;
         if (ok && (p.flags & F_STORE_GATE) != 0) st4e<C16>(C2b, lr * ldc2 + col4, m);
+        if (pool && ok) {      // a lane walks its rows in increasing order: strict > keeps the first maximum
+          if (C16) { v.x = bf16_round(v.x); v.y = bf16_round(v.y); v.z = bf16_round(v.z); v.w = bf16_round(v.w); }
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (vv[e] > pmx[e]) { pmx[e] = vv[e]; pix[e] = lr; }
+            psm[e] += vv[e];
+          }
+        }
       } else {
         if (resid) { v.x += z.x; v.y += z.y; v.z += z.z; v.w += z.w; }
         if ((p.flags & F_RELU_OUT) != 0) {
@@ -531,6 +547,23 @@ __device__ __forceinline__ void nt_epilogue_vec(ACC& acc, const NTParams& p, int
     // 9 GB of scratch writes per fusion-dgrad launch at B=4096)
     if (EPI == EPI_DGRAD)
       asm volatile("" : "+v"(s1.x), "+v"(s1.y), "+v"(s1.z), "+v"(s1.w), "+v"(s2.x), "+v"(s2.y), "+v"(s2.z), "+v"(s2.w));
+  }
+  if (pool) {
+    // combine the 4 row groups (lane bits 4, 5): larger value wins, ties go to the smaller row
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int o = 16; o <= 32; o <<= 1) {
+        const float ov = __shfl_xor(pmx[e], o);
+        const int oi = __shfl_xor(pix[e], o);
+        psm[e] += __shfl_xor(psm[e], o);
+        if (ov > pmx[e] || (ov == pmx[e] && oi < pix[e])) { pmx[e] = ov; pix[e] = oi; }
+      }
+    if (lane < 16 && c4ok) {
+      *reinterpret_cast<float4*>(p.ws_a + (size_t)rb * p.N + col4) = make_float4(pmx[0], pmx[1], pmx[2], pmx[3]);
+      *reinterpret_cast<float4*>(p.ws_b + (size_t)rb * p.N + col4) = make_float4(psm[0], psm[1], psm[2], psm[3]);
+      *reinterpret_cast<int4*>(p.ws_c + (size_t)rb * p.N + col4) = make_int4(pix[0], pix[1], pix[2], pix[3]);
+    }
   }
   if (EPI == EPI_DGRAD && (p.flags & F_STATS) != 0) {
     // column sums: reduce over the 4 row groups (lane bits 4,5)

@@ -260,6 +260,28 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ F, 
   }
 }
 
+// Dual pooling from the per-tile partials the gate epilogue wrote (F_POOL): a segment of N
+// points = N / 128 consecutive 128-row wave tiles (N % 128 == 0).  First-index ties: tiles in
+// order, strict >.  grid = (ceil(C/256), B).
+__global__ __launch_bounds__(256) void pool_tiles_kernel(const float* __restrict__ pmax,
+                                                         const float* __restrict__ psum,
+                                                         const int* __restrict__ pidx, int tiles_per_seg,
+                                                         int N, int C, float* gfeat, int32_t* argmax) {
+  const int col = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (col >= C) return;
+  float mx = -INFINITY, sum = 0.f;
+  int ix = 0;
+  for (int t = 0; t < tiles_per_seg; ++t) {
+    const size_t o = ((size_t)b * tiles_per_seg + t) * C + col;
+    const float v = pmax[o];
+    if (v > mx) { mx = v; ix = t * 128 + pidx[o]; }
+    sum += psum[o];
+  }
+  gfeat[(size_t)b * 2 * C + col] = mx;
+  gfeat[(size_t)b * 2 * C + C + col] = sum / (float)N;
+  if (argmax != nullptr) argmax[(size_t)b * C + col] = ix;
+}
+
 // ---------------------------------------------------------------------------------------
 // Backward of  F = relu(zf*s+t) * m,  gfeat = [max_n F | mean_n F]   (src/model.py:51-60)
 //   dF_total = dF (may be null) + d_mean/N + [n == argmax] * d_max

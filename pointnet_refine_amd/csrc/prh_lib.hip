@@ -132,6 +132,8 @@ bool g_h2_gen2 = [] { const char* e = getenv("PRH_H2_GEN"); return !(e && strcmp
 int g_tn_skew = [] { const char* e = getenv("PRH_TN_SKEW"); return e ? atoi(e) : 0; }();   // diagnostic
 bool g_tn_pace = [] { const char* e = getenv("PRH_TN_PACE"); return !(e && strcmp(e, "0") == 0); }();
 bool g_tn_tr = [] { const char* e = getenv("PRH_TN_TR"); return !(e && strcmp(e, "0") == 0); }();
+// PRH_POOL_FUSED=0 keeps the dual pooling a separate pass over `fused` (A/B comparison)
+bool g_pool_fused = [] { const char* e = getenv("PRH_POOL_FUSED"); return !(e && strcmp(e, "0") == 0); }();
 inline const char* core_tag() { return core_mode() == 2 ? "b1" : (core_mode() == 3 ? "h2" : "s3"); }
 
 // largest |pro(A)| over [rows, cols] into *slot; part: ABSMAX_MAX_BLOCKS floats of scratch
@@ -328,6 +330,10 @@ int launch_nt(NTParams& p, hipStream_t st, StatInfo* si = nullptr) {   // p.amax
   if constexpr (PRO == PRO_NONE && EPI == EPI_BIAS) {
     if (gemm_mode() == 4 && nt_b16_generic_ok(p)) return launch_nt_b16<PRO_NONE, EPI_BIAS, false, false>(p, st, si);
   }
+  // F_POOL is honoured by the vector epilogue only: cleared here, set again by the branch that
+  // launches a kernel with that epilogue, so the caller can tell whether the partials exist
+  const bool want_pool = (p.flags & F_POOL) != 0;
+  p.flags &= ~F_POOL;
   char nm[64];
   // algorithmic traffic: A (+A2) read once, C written once (+E1/C_old reads), W read once
   const double by = 4.0 * ((double)p.M * p.K * (PRO == PRO_BNBWD ? 2 : (PRO == PRO_GATE1 ? 0 : 1)) +
@@ -364,6 +370,7 @@ int launch_nt(NTParams& p, hipStream_t st, StatInfo* si = nullptr) {   // p.amax
                              p.N, p.K, p.ldw, p.wprep + S3_WHDR, p.amaxW);
           LAUNCH_CHECK();
           p.tiles_n = NTl;
+          if (want_pool) p.flags |= F_POOL;
           static const int attr_h2 = allow_big_lds(gemm_nt_h2_kernel<PRO, EPI>);
           if (attr_h2 != PRH_OK) return attr_h2;
           snprintf(nm, sizeof(nm), "gemm_nt_h2<%d,%d> K=%d N=%d", PRO, EPI, p.K, p.N);
@@ -887,7 +894,7 @@ void enc_carve(Arena& a, EncWS& e, int P, const prh_bn_layer* conv, int cat, int
 // ---- bf16 mode: workspace layouts and small launch helpers
 typedef unsigned short u16;
 struct Enc16WS {
-  u16* xpad; float* w0pad; float* ws_a; float* ws_b; double* stat2; char* wprep;
+  u16* xpad; float* w0pad; float* ws_a; float* ws_b; float* ws_c; double* stat2; char* wprep;
   float *ca, *cb, *cc, *wT, *slab, *cslab, *dU, *gsum_a, *gsum_b; u16 *dy_cat, *dyf;
 };
 inline int cin_pad8(int c) { return (c + 7) / 8 * 8; }
@@ -898,6 +905,7 @@ void enc16_carve(Arena& a, Enc16WS& e, int P, const int* ch /*[6]: cin, 64..od*/
   e.w0pad = a.f((size_t)ch[1] * c0p);
   e.ws_a = a.f((size_t)stat_tiles_max(P) * maxc);
   e.ws_b = a.f((size_t)stat_tiles_max(P) * maxc);
+  e.ws_c = a.f((size_t)stat_tiles_max(P) * od);          // pooling partials (arg-max rows)
   e.stat2 = (double*)a.f((size_t)BN_SLICES * 3 * maxc * 2);
   size_t wb = b16_weight_bytes(od, cat), t = b16_weight_bytes(cat, od);
   wb = t > wb ? t : wb;
@@ -1360,9 +1368,20 @@ int prh_encoder_forward(const prh_encoder_params* prm, const float* ctx, int B, 
     p.C = fused; p.ldc = od; p.C2 = sv->gate; p.ldc2 = od;
     p.wprep = w.wprep;
     p.flags = sv->gate ? F_STORE_GATE : 0;
+    // dual pooling (src/model.py:58-60) on the epilogue that writes `fused`, when a segment is a
+    // whole number of 128-row wave tiles and the vector epilogue serves the launch
+    const bool fuse_pool = gfeat != nullptr && (N % 128) == 0 && g_pool_fused && gemm_mode() == 3 && g_h2_gen2 &&
+                           nt_use_s3(P, od, 64) && (od & 3) == 0;
+    if (fuse_pool) { p.flags |= F_POOL; p.ws_a = w.ws_a; p.ws_b = w.ws_b; p.ws_c = w.ws_c; }
     TRY((launch_nt<PRO_GATE1, EPI_GATE>(p, st)));
+    if ((p.flags & F_POOL) != 0) {
+      hipLaunchKernelGGL(pool_tiles_kernel, dim3(cdiv(od, 256), B), dim3(256), 0, st, (const float*)w.ws_a,
+                         (const float*)w.ws_b, (const int*)w.ws_c, N / 128, N, od, gfeat, sv->argmax);
+      LAUNCH_CHECK();
+      return PRH_OK;
+    }
   }
-  // dual pooling                                                   src/model.py:58-60
+  // dual pooling as a pass of its own                              src/model.py:58-60
   if (gfeat != nullptr) {
     hipLaunchKernelGGL(pool_kernel, dim3(cdiv(od, 64), B), dim3(256), 0, st, fused, N, od, gfeat,
                        sv->argmax);
@@ -1561,7 +1580,15 @@ int prh_encoder_forward_bf16(const prh_encoder_params* prm, const float* ctx, in
     p.C = f16p(fused); p.ldc = od; p.C2 = f16p(sv->gate); p.ldc2 = od;
     p.wprep = w.wprep;
     p.flags = sv->gate ? F_STORE_GATE : 0;
+    const bool fuse_pool = gfeat != nullptr && (N % 128) == 0 && g_pool_fused;
+    if (fuse_pool) { p.flags |= F_POOL; p.ws_a = w.ws_a; p.ws_b = w.ws_b; p.ws_c = w.ws_c; }
     TRY((launch_nt_b16<PRO_GATE1, EPI_GATE, true, true>(p, st)));
+    if (fuse_pool) {
+      hipLaunchKernelGGL(pool_tiles_kernel, dim3(cdiv(od, 256), B), dim3(256), 0, st, (const float*)w.ws_a,
+                         (const float*)w.ws_b, (const int*)w.ws_c, N / 128, N, od, gfeat, sv->argmax);
+      LAUNCH_CHECK();
+      return PRH_OK;
+    }
   }
   if (gfeat != nullptr) {
     hipLaunchKernelGGL(pool_b16_kernel, dim3(cdiv(od, 64), B), dim3(256), 0, st, (const u16*)fused, N, od, gfeat, sv->argmax);
@@ -2033,7 +2060,8 @@ int prh_attn_forward(const float* q, long ldq, const float* k, long ldk, const f
   HIP_TRY(hipSetDevice(device));
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps("attn_fwd", 4.0 * B * H * (double)M * N * 32, 4.0 * (2.0 * B * N * H * 32 + 2.0 * B * M * H * 32), st);
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(B * (H / 4))), dim3(256), 0, st, a);
+  const int wpb = (long)B * (H / 4) < 512 ? 1 : 4;      // one head per workgroup while the grid would not fill the chip
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(B * (H / wpb))), dim3(64 * wpb), 0, st, a);
   LAUNCH_CHECK();
   return PRH_OK;
 }
@@ -2057,14 +2085,15 @@ int prh_attn_backward_ex(const float* q, long ldq, const float* k, long ldk, con
   if ((lddo | lddq | lddk | lddv) & 3) return fail(PRH_ERR_ARG, "attention_backward: leading dimensions must be multiples of 4");
   HIP_TRY(hipSetDevice(device));
   hipStream_t st = (hipStream_t)stream;
-  const size_t lds = (size_t)4 * 4 * AT_TILE * sizeof(float);
+  const int wpb = (long)B * (H / 4) < 512 ? 1 : 4;
+  const size_t lds = (size_t)wpb * 4 * AT_TILE * sizeof(float);
   static const int attr_rc = [] {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 0 : 1;
   }();
   if (attr_rc) return fail(PRH_ERR_HIP, "attention_backward: cannot raise the dynamic LDS limit");
   ProfScope ps("attn_bwd", 14.0 * B * H * (double)M * N * 32, 4.0 * (4.0 * B * N * H * 32 + 4.0 * B * M * H * 32), st);
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(B * (H / 4))), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(B * (H / wpb))), dim3(64 * wpb), lds, st, a);
   LAUNCH_CHECK();
   return PRH_OK;
 }

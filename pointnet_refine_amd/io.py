@@ -73,10 +73,16 @@ def load_scene_items(json_path):
 
 @torch.no_grad()
 def refine_scene(model, pcd_points, raw_lines, num_line_points=32, num_context_points=1024,
-                 crop_radius=0.3, decay_scale=2.0, batch_lines=512, seed=0):
+                 crop_radius=0.3, decay_scale=2.0, batch_lines=512, seed=0, precision=None):
     """Refine every polyline of a scene (inference_whole_scene.py:94-146, NUM_CONTEXT_POINTS 1024,
     CROP_RADIUS 0.3).  pcd_points (P,4) numpy or CUDA tensor; raw_lines list of (n_i,3).
-    Returns (refined (L,M,3), noisy_resampled (L,M,3)) numpy arrays in scene coordinates."""
+    Returns (refined (L,M,3), noisy_resampled (L,M,3)) numpy arrays in scene coordinates.
+
+    The eval forward takes the fused encoder kernel (csrc/prh_fused.hpp: context -> memory in one
+    launch).  precision: None = the model's setting (fp32-accurate by default); "fp32"; "fp16" =
+    BASELINE config 5's batched reduced-precision forward - encoder on one fp16 plane, decoder
+    GEMMs on one bf16 plane (GEMM mode 4) for the duration of the call; "layers" = the per-layer
+    kernels (the round-1 path, kept for comparison)."""
     dev = next(model.parameters()).device
     cloud = pcd_points if torch.is_tensor(pcd_points) else torch.from_numpy(np.ascontiguousarray(pcd_points, dtype=np.float32))
     cloud = cloud.to(dev, torch.float32)
@@ -86,7 +92,17 @@ def refine_scene(model, pcd_points, raw_lines, num_line_points=32, num_context_p
         return np.zeros((0, num_line_points, 3)), np.zeros((0, num_line_points, 3))
     was_training = model.training
     model.eval()
+    from . import _lib as _L
+    enc = getattr(model, "context_encoder", None)
+    old_prec = getattr(enc, "inference_precision", None)
+    old_mode = _L.lib().prh_get_gemm_mode()
+    if precision not in (None, "fp32", "fp16", "layers"):
+        raise ValueError("refine_scene: precision must be None, 'fp32', 'fp16' or 'layers'")
     try:
+        if precision is not None and enc is not None:
+            enc.inference_precision = None if precision == "layers" else precision
+        if precision == "fp16":
+            _L.check(_L.lib().prh_set_gemm_mode(4), "prh_set_gemm_mode")
         ctx, noisy_c, centres, _ = build_contexts(cloud, raw_lines, num_line_points, num_context_points,
                                                   crop_radius, decay_scale, seed)
         outs = []
@@ -97,6 +113,9 @@ def refine_scene(model, pcd_points, raw_lines, num_line_points=32, num_context_p
         return (noisy + offset).cpu().numpy(), noisy.cpu().numpy()                         # :146
     finally:
         model.train(was_training)
+        if enc is not None:
+            enc.inference_precision = old_prec
+        _L.lib().prh_set_gemm_mode(old_mode)
 
 
 class SceneSampleStream:

@@ -188,3 +188,45 @@ def test_encoder_train_ragged_large_vs_oracle_on_split_cores():
     msd = m.state_dict()
     for k, v in ns.items():
         assert maxdiff(msd[k], v) <= 1e-5 * float(v.double().abs().max()) + 1e-6, k
+
+
+@pytest.mark.parametrize("gemm_mode,B,N", [(3, 4, 512), (3, 2, 1024), (4, 3, 256)])
+def test_pooling_fused_into_the_gate_epilogue(gemm_mode, B, N):
+    """Segments of a whole number of 128-row wave tiles: the dual pooling (src/model.py:58-60)
+    rides on the epilogue that writes `fused` (F_POOL + pool_tiles_kernel) instead of a pass of its
+    own.  Forward against the oracle, and the backward with upstream gradient on global_feat ONLY,
+    so every parameter gradient flows through the arg-max rows the epilogue recorded - incl. a
+    dead channel, whose maximum ties at 0 on every point (first index wins)."""
+    from pointnet_refine_amd import _lib
+    lib = _lib.lib()
+    old = lib.prh_get_gemm_mode()
+    sd = P.encoder_state_dict(4, 1024, seed=3)
+    sd["fusion.1.weight"][5] = 0.0
+    sd["fusion.1.bias"][5] = -1.0
+    ctx, _, _ = P.synth_batch(B, N, 4, 32, seed=31)
+    up_g = torch.from_numpy(np.random.default_rng(2).normal(0, 1, (B, 2048)).astype(np.float32))
+    try:
+        lib.prh_set_gemm_mode(gemm_mode)
+        m = _encoder(4, sd).train()
+        x = ctx.cuda().requires_grad_(True)
+        gf, fu = m(x.transpose(2, 1))
+        (gf * up_g.cuda()).sum().backward()
+    finally:
+        lib.prh_set_gemm_mode(old)
+    p = O.as_params(sd, requires_grad=True)
+    ox = ctx.clone().requires_grad_(True)
+    o_g, o_f = O.encoder_forward(p, ox, "", True, {})
+    (o_g * up_g).sum().backward()
+    named = dict(m.named_parameters())
+    if gemm_mode == 3:
+        assert maxdiff(gf, o_g) < 1e-4 and maxdiff(fu.transpose(2, 1), o_f) < 1e-4
+        assert rel_l2(ox.grad, x.grad) < 5e-3
+        assert rel_l2(p["fusion.0.weight"].grad.reshape(named["fusion.0.weight"].shape), named["fusion.0.weight"].grad) < 5e-3
+        # the dead channel: gradient of its maximum went to point 0 of every segment, as torch.max does
+        assert rel_l2(p["intensity_gate.2.bias"].grad, named["intensity_gate.2.bias"].grad) < 5e-3
+    else:
+        # bf16 storage: reduced-precision gates (tests/test_bf16_gpu.py).  With the gradient entering
+        # through the max-pool only, a near-tie between two points that bf16 rounding resolves the
+        # other way moves that channel's whole gradient to another point: measured 0.22 on fusion dW
+        assert rel_l2(o_g, gf) < 3e-2
+        assert rel_l2(p["fusion.0.weight"].grad.reshape(named["fusion.0.weight"].shape), named["fusion.0.weight"].grad) < 0.4
