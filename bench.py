@@ -54,8 +54,8 @@ MODE_INFO = {
     3: (3, BF16_MFMA_PEAK_TFLOPS, "2500 TF dense fp16 MFMA / 3 products per fp32-accurate MAC (2 scaled fp16 planes)",
         "f32 (large GEMMs: 2xfp16-split MFMA, 3 products, fp32 accumulate)"),
     4: (1, BF16_MFMA_PEAK_TFLOPS, "2500 TF dense bf16 MFMA (v_mfma_f32_16x16x32_bf16)",
-        "bf16 (encoder activations and their gradients stored in bf16, bf16 MFMA operands everywhere; "
-        "fp32 accumulate, statistics, attention core, master weights and optimiser)"),
+        "bf16 (encoder activations and their gradients stored in bf16, bf16 MFMA operands in every GEMM; "
+        "fp32 accumulate, statistics, master weights and optimiser; attention core on split-fp16 products)"),
 }
 
 
@@ -82,6 +82,11 @@ def parse():
     ap.add_argument("--kernels", type=int, default=0, help="print the K longest GEMM launches (live HIP-event times) to stderr")
     ap.add_argument("--cpu-batch", type=int, default=16,
                     help="segments in the CPU sample (16: the host's best throughput; 64 measured 2.5x slower per segment)")
+    ap.add_argument("--encoder-only", action="store_true",
+                    help="second workload (not the headline metric): MultiScalePointNetEncoder.forward returning "
+                         "(global_feat, fused) - the north_star's fused shared-MLP + max-pool - alone: train-mode "
+                         "forward+backward, or with --eval the inference forward through the single fused kernel")
+    ap.add_argument("--eval", action="store_true", help="with --encoder-only: eval-mode forward only (fused kernel)")
     ap.add_argument("--stub", action="store_true",
                     help="launcher self-test: a small CPU stand-in model over the gloo backend instead of "
                          "the HIP model over RCCL (tests/test_bench_launcher_cpu.py); not a measurement")
@@ -411,10 +416,14 @@ def run(args):
             # achieved = ALGORITHMIC FLOPs (2*M*N*K) / live launch time.  Peak of the core the
             # kernel runs on: the exact fp32 MFMA pipe, or the dense 16-bit MFMA peak divided by
             # the products the core issues per algorithmic MAC.
-            on_fp32_core = not any(t in dname for t in ("_s3", "_b1", "_h2", "_b16"))
+            on_fp32_core = not any(t in dname for t in ("_s3", "_b1", "_h2", "_b16", "attn16", "encoder_fused"))
             products, peak16, basis, _ = MODE_INFO[mode]
             if on_fp32_core:
                 products, peak16, basis = 1, FP32_MFMA_PEAK_TFLOPS, MODE_INFO[0][2]
+            elif "<split>" in dname:              # attention cores: three fp16 products whatever the GEMM mode
+                products, peak16, basis = MODE_INFO[3][:3]
+            elif "<bf16>" in dname:
+                products, peak16, basis = MODE_INFO[4][:3]
             peak = peak16 / products
             traffic, tfile = pmc_traffic(dname, B, N, mode)
             sf = step_flops(B, N)
@@ -502,8 +511,116 @@ def run(args):
     return 0
 
 
+def run_encoder(args):
+    """--encoder-only: the encoder API path (src/model.py:39-62) with both returns live."""
+    import ctypes as C
+    import torch
+    from pointnet_refine_amd import _lib
+    from pointnet_refine_amd.model import MultiScalePointNetEncoder
+    from pointnet_refine_amd.synth import synthetic_batch
+    if args.gpus != 1 or "RANK" in os.environ:
+        raise SystemExit("--encoder-only is a single-GPU measurement (replicas only: no exchange on this path)")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    lib = _lib.lib()
+    mode = GEMM_MODES[args.gemm]
+    _lib.check(lib.prh_set_gemm_mode(mode), "prh_set_gemm_mode")
+    B, N = args.batch, args.points
+    torch.manual_seed(0)
+    enc = MultiScalePointNetEncoder(4, 1024).to(dev)
+    ctx, _, _ = synthetic_batch(B, N, dev, seed=1234)
+    x_cm = ctx.transpose(2, 1)                       # the reference's (B, C, N) view; read in place, never copied
+    flop_seg = 5_587_584.0 * N                       # SURVEY 8(d): encoder forward, 2 * 2,793,792 MAC per point
+    if args.eval:
+        enc.eval()
+        enc.inference_precision = "fp16" if mode == 4 else "fp32"
+        ctx_pm = ctx
+
+        def step():
+            with torch.no_grad():
+                return enc.forward_pointmajor(ctx_pm, True)
+        what = (f"eval forward, ONE fused kernel (BatchNorm folded, pooling in the epilogue), "
+                f"{'one fp16 plane' if mode == 4 else 'two fp16 planes / three products, fp32-level error'}")
+        flops = flop_seg * B
+        bytes_seg = 16.0 * N + 4096.0 * N + 8192.0    # SURVEY 8(d)(ii): context in, fused fp32 + global_feat out
+    else:
+        enc.train()
+        up_g = torch.randn(B, 2048, device=dev)
+        up_f = torch.randn(B, N, 1024, device=dev, dtype=torch.bfloat16 if mode == 4 else torch.float32)
+
+        def step():
+            for p_ in enc.parameters():
+                p_.grad = None
+            gf, fu = enc.forward_pointmajor(ctx, True)
+            torch.autograd.backward([gf, fu], [up_g, up_f])
+            return gf, fu
+        what = "train-mode forward + backward (batch statistics), gradients on global_feat and fused"
+        flops = 3.0 * flop_seg * B
+        bytes_seg = None
+    for i in range(args.warmup):
+        step()
+        torch.cuda.synchronize(dev)
+        log(f"warmup {i} done, mem {torch.cuda.max_memory_allocated(dev) / 2**30:.1f} GiB")
+    lib.prh_profile_enable(min(262144, (args.steps + 1) * 200))
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    agg = {}
+    name = C.create_string_buffer(64)
+    ms, fl, by = C.c_float(), C.c_double(), C.c_double()
+    for i in range(lib.prh_profile_count()):
+        lib.prh_profile_read(i, name, 64, C.byref(ms), C.byref(fl), C.byref(by))
+        a = agg.setdefault(name.value.decode(), [0, 0.0, fl.value, by.value])
+        a[0] += 1
+        a[1] += ms.value
+    lib.prh_profile_enable(0)
+    if args.kernels > 0:
+        for k, (c, t, f, _) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:args.kernels]:
+            print(f"[bench] {k:44s} x{c:4d} {t / c:8.3f} ms  {f / (t / c * 1e-3) / 1e12:7.1f} TF", file=sys.stderr)
+    dname, (cnt, tot_ms, kflops, kbytes) = max(agg.items(), key=lambda kv: kv[1][1])
+    avg_ms = tot_ms / cnt
+    products, peak16, basis, dtype = MODE_INFO[mode]
+    if args.eval:
+        products = 1 if mode == 4 else 3
+        peak16, basis = BF16_MFMA_PEAK_TFLOPS, ("2500 TF dense fp16 MFMA" + ("" if mode == 4 else " / 3 products per fp32-accurate MAC"))
+        dtype = "fp16 operands, fp32 accumulate" if mode == 4 else "f32 (2xfp16-split MFMA, 3 products, fp32 accumulate)"
+    elif not any(t in dname for t in ("_s3", "_b1", "_h2", "_b16")):
+        products, peak16, basis = 1, FP32_MFMA_PEAK_TFLOPS, MODE_INFO[0][2]
+    peak = peak16 / products
+    ach = kflops / (avg_ms * 1e-3) / 1e12
+    line = {"metric": "lane segments/sec, MultiScalePointNetEncoder alone (shared MLP + fusion + gate + max/mean pool); "
+                      "HBM GB/s vs roofline",
+            "value": round(B * args.steps / dt, 2), "unit": "segments/s", "n_gpus": 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": f"MultiScalePointNetEncoder (global_feat, fused), {what}, B={B}, N={N}, C=4",
+                       "global_batch": B, "points": N, "parallelism": "dp1"},
+            "max_mem_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1),
+            "roofline": {"bound": "mfma", "kernel": dname, "achieved": round(ach, 2), "peak": round(peak, 1),
+                         "unit": "TFLOP/s", "frac": round(ach / peak, 4), "peak_basis": basis,
+                         "avg_launch_ms": round(avg_ms, 4), "launches": cnt, "traffic": None,
+                         "algorithmic_bytes": kbytes,
+                         "algorithmic_gbs": round(kbytes / (avg_ms * 1e-3) / 1e9, 1),
+                         "hbm_frac": round(kbytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "step": {"flops": flops, "achieved_tflops": round(flops / (dt / args.steps) / 1e12, 1),
+                                  "peak": round(peak, 1), "frac": round(flops / (dt / args.steps) / 1e12 / peak, 4)}}}
+    if bytes_seg is not None:
+        gbs = bytes_seg * B / (dt / args.steps) / 1e9
+        line["hbm"] = {"algorithmic_bytes_per_segment": bytes_seg, "achieved_gbs": round(gbs, 1),
+                       "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 4),
+                       "note": "compulsory traffic only (context in, fused + global_feat out): the kernel is bound "
+                               "by the matrix pipe and L2 weight streaming, not by HBM (SURVEY D8)"}
+    print(json.dumps(line), flush=True)
+    return 0
+
+
 def main():
     args = parse()
+    if args.encoder_only:
+        return run_encoder(args)
     if args.gpus > 1 and "RANK" not in os.environ:
         return launch_ranks(args)
     return run(args)

@@ -16,6 +16,7 @@
 
 #include "prh_gemm.hpp"
 #include "prh_attn.hpp"
+#include "prh_attn16.hpp"
 #include "prh_gemm_s3.hpp"
 #include "prh_gemm_h2.hpp"
 #include "prh_b16.hpp"
@@ -133,6 +134,18 @@ int g_tn_skew = [] { const char* e = getenv("PRH_TN_SKEW"); return e ? atoi(e) :
 bool g_tn_pace = [] { const char* e = getenv("PRH_TN_PACE"); return !(e && strcmp(e, "0") == 0); }();
 bool g_tn_tr = [] { const char* e = getenv("PRH_TN_TR"); return !(e && strcmp(e, "0") == 0); }();
 // PRH_POOL_FUSED=0 keeps the dual pooling a separate pass over `fused` (A/B comparison)
+// Attention cores: 16-bit MFMA (two fp16 planes / three products with the fp32-accurate GEMM modes,
+// one bf16 plane in the bf16 modes); PRH_ATTN=fp32 or GEMM mode 0 keep the exact fp32 MFMA kernels
+bool g_attn_fp32 = [] { const char* e = getenv("PRH_ATTN"); return e && strcmp(e, "fp32") == 0; }();
+bool g_attn_bf16 = [] { const char* e = getenv("PRH_ATTN"); return e && strcmp(e, "bf16") == 0; }();
+// -1: exact fp32 MFMA kernels (GEMM mode 0, PRH_ATTN=fp32); 0: two fp16 planes, three products - every
+// other mode, the bf16 modes included: at B=4096 one bf16 plane saves 12 ms of a 300 ms step and
+// triples the worst per-tensor gradient error (0.29 against 0.064 vs the exact cores); 1: one bf16
+// plane (PRH_ATTN=bf16, measurement only)
+inline int attn_prec() {
+  if (g_attn_fp32 || gemm_mode() == 0) return -1;
+  return g_attn_bf16 ? 1 : 0;
+}
 bool g_pool_fused = [] { const char* e = getenv("PRH_POOL_FUSED"); return !(e && strcmp(e, "0") == 0); }();
 inline const char* core_tag() { return core_mode() == 2 ? "b1" : (core_mode() == 3 ? "h2" : "s3"); }
 
@@ -2059,9 +2072,17 @@ int prh_attn_forward(const float* q, long ldq, const float* k, long ldk, const f
   TRY(check_attn(a));
   HIP_TRY(hipSetDevice(device));
   hipStream_t st = (hipStream_t)stream;
-  ProfScope ps("attn_fwd", 4.0 * B * H * (double)M * N * 32, 4.0 * (2.0 * B * N * H * 32 + 2.0 * B * M * H * 32), st);
+  const int prec_ = attn_prec();
+  ProfScope ps(prec_ < 0 ? "attn_fwd" : (prec_ == 0 ? "attn16_fwd<split>" : "attn16_fwd<bf16>"),
+               4.0 * B * H * (double)M * N * 32, 4.0 * (2.0 * B * N * H * 32 + 2.0 * B * M * H * 32), st);
   const int wpb = (long)B * (H / 4) < 512 ? 1 : 4;      // one head per workgroup while the grid would not fill the chip
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(B * (H / wpb))), dim3(64 * wpb), 0, st, a);
+  const int prec = attn_prec();
+  if (prec == 0)
+    hipLaunchKernelGGL(attn16_fwd_kernel<0>, dim3((unsigned)(B * (H / wpb))), dim3(64 * wpb), 0, st, a);
+  else if (prec == 1)
+    hipLaunchKernelGGL(attn16_fwd_kernel<1>, dim3((unsigned)(B * (H / wpb))), dim3(64 * wpb), 0, st, a);
+  else
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(B * (H / wpb))), dim3(64 * wpb), 0, st, a);
   LAUNCH_CHECK();
   return PRH_OK;
 }
@@ -2086,6 +2107,24 @@ int prh_attn_backward_ex(const float* q, long ldq, const float* k, long ldk, con
   HIP_TRY(hipSetDevice(device));
   hipStream_t st = (hipStream_t)stream;
   const int wpb = (long)B * (H / 4) < 512 ? 1 : 4;
+  const int prec = attn_prec();
+  if (prec >= 0) {
+    const size_t lds16 = (size_t)wpb * (3 * (prec == 0 ? 2 : 1) * A16_IMG + AT_TILE * 4);
+    static const int attr16 = [] {
+      return (hipFuncSetAttribute(reinterpret_cast<const void*>(attn16_bwd_kernel<0>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+              hipFuncSetAttribute(reinterpret_cast<const void*>(attn16_bwd_kernel<1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess) ? 0 : 1;
+    }();
+    if (attr16) return fail(PRH_ERR_HIP, "attention_backward: cannot raise the dynamic LDS limit");
+    ProfScope ps(prec == 0 ? "attn16_bwd<split>" : "attn16_bwd<bf16>", 14.0 * B * H * (double)M * N * 32, 4.0 * (4.0 * B * N * H * 32 + 4.0 * B * M * H * 32), st);
+    if (prec == 0)
+      hipLaunchKernelGGL(attn16_bwd_kernel<0>, dim3((unsigned)(B * (H / wpb))), dim3(64 * wpb), lds16, st, a);
+    else
+      hipLaunchKernelGGL(attn16_bwd_kernel<1>, dim3((unsigned)(B * (H / wpb))), dim3(64 * wpb), lds16, st, a);
+    LAUNCH_CHECK();
+    return PRH_OK;
+  }
   const size_t lds = (size_t)wpb * 4 * AT_TILE * sizeof(float);
   static const int attr_rc = [] {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel),
