@@ -42,7 +42,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0     # dense v_mfma_f32_{32x32x16,16x16x32}_{bf16,
 HBM_PEAK_GBS = 8000.0
 GEMM_MODES = {"fp32": 0, "split": 1, "bf16op": 2, "split16": 3, "bf16": 4}
 DEFAULT_GEMM = "split16"
-PMC_TRAFFIC_FILES = {3: "r01q_pmc_traffic_B4096.json"}      # gemm mode -> committed PMC pass
+PMC_TRAFFIC_FILES = {3: "r02k_pmc_traffic_B4096_split16.json", 4: "r02k_pmc_traffic_B4096_bf16.json"}   # gemm mode -> committed PMC pass
 # MFMA products issued per algorithmic MAC and what the peak is quoted on, per gemm mode
 MODE_INFO = {
     0: (1, FP32_MFMA_PEAK_TFLOPS, "157.3 TF fp32 MFMA (v_mfma_f32_32x32x2_f32)",
@@ -194,12 +194,18 @@ def pmc_traffic(dname, batch, points, mode):
     path = os.path.join(ROOT, "profiles", fn)
     if not os.path.exists(path):
         return None, None
+    recs = json.load(open(path))
+    ma = re.match(r"attn16_(fwd|bwd)<(split|bf16)>", dname)
     m = re.match(r"gemm_(nt|tn)_(h2|b16)(tr)?<(\d),(\d)>", dname)
-    if not m:
+    if ma:
+        tmpl = f"prh::attn16_{ma.group(1)}_kernel<{0 if ma.group(2) == 'split' else 1}>"
+        cands = [r for r in recs if r["kernel"] == tmpl]
+    elif not m:
         return None, fn
-    if m.group(2) == "b16":
-        tmpl = ("prh::gemm_tn_b16_kernel" if m.group(1) == "tn" else "prh::gemm_nt_b16_kernel")
-        cands = [r for r in json.load(open(path)) if r["kernel"].startswith(tmpl)]
+    elif m.group(2) == "b16":
+        tmpl = (f"prh::gemm_tn_b16_kernel<{m.group(5)}>" if m.group(1) == "tn"
+                else f"prh::gemm_nt_b16_kernel<{m.group(4)}, {m.group(5)},")
+        cands = [r for r in recs if r["kernel"].startswith(tmpl)]
     else:
         if m.group(1) == "tn" and m.group(3):      # wgrad core with transposed fragment reads
             tmpl = f"prh::gemm_tn_tr_kernel<{m.group(5)}>"
@@ -207,7 +213,7 @@ def pmc_traffic(dname, batch, points, mode):
             tmpl = f"prh::gemm_tn_s3_kernel<{m.group(4)}, {m.group(5)}, 2>"
         else:
             tmpl = f"prh::gemm_nt_h2_kernel<{m.group(4)}, {m.group(5)}>"
-        cands = [r for r in json.load(open(path)) if r["kernel"] == tmpl]
+        cands = [r for r in recs if r["kernel"] == tmpl]
     if not cands:
         return None, fn
     r = max(cands, key=lambda r: r["fetch_bytes_largest_launch"])      # the fusion-layer launch

@@ -11,6 +11,7 @@ import os
 import sys
 
 d, out = sys.argv[1], sys.argv[2]
+MIN_BYTES = float(sys.argv[3]) if len(sys.argv) > 3 else 1e9      # skip launches that fetch less than this
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(os.path.join(d, c, "**", "*counter_collection.csv"), recursive=True)
@@ -19,7 +20,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     per = collections.defaultdict(float)
     meta = {}
     for r in csv.DictReader(open(f[0])):
-        if "prh::gemm" not in r["Kernel_Name"] and "prh::attn" not in r["Kernel_Name"]:
+        if "prh::" not in r["Kernel_Name"]:
             continue
         per[r["Dispatch_Id"]] += float(r["Counter_Value"])
         meta[r["Dispatch_Id"]] = (r["Kernel_Name"].split("(")[0].replace("void ", ""), int(r["Grid_Size"]) // int(r["Workgroup_Size"]))
@@ -29,7 +30,7 @@ res = []
 for (name, wgs), m in acc.items():
     fe = m.get("FETCH_SIZE", [])
     wr = m.get("WRITE_SIZE", [])
-    if not fe or max(fe) * 2048 < 1e9:
+    if not fe or max(fe) * 2048 < MIN_BYTES:
         continue
     # launches of one template with one grid can still be different layers (every wgrad runs
     # 768 workgroups): keep the average and the largest launch of the group (dispatch order is
@@ -43,7 +44,7 @@ for (name, wgs), m in acc.items():
                 "note": "FETCH_SIZE x2 (gfx950 half-count correction), WRITE_SIZE as read; separate --pmc passes"})
 res.sort(key=lambda r: -r["fetch_bytes_largest_launch"])
 json.dump(res, open(out, "w"), indent=1)
-for r in res[:10]:
+for r in res[:16]:
     print(f"{r['kernel'][:48]:48s} wgs={r['workgroups']:7d} n={r['launches']:3d} fetch avg {r['fetch_bytes_per_launch']/1e9:7.2f} GB "
           f"largest {r['fetch_bytes_largest_launch']/1e9:7.2f} GB  write avg {(r['write_bytes_per_launch'] or 0)/1e9:7.2f} "
           f"largest {(r['write_bytes_largest_launch'] or 0)/1e9:7.2f} GB")
