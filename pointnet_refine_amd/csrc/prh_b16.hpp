@@ -139,7 +139,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_b16_kernel(const NTParams p, c
 
   // staging registers: A16: one uint4 (8 bf16) per row pass, A32: two float4
   constexpr int RW = A16 ? 1 : 2;
-  uint4 ra[2][4][RW];
+  uint4 ra[A16 ? 2 : 1][4][RW];
   const char* wsrc = Wp + (size_t)tile_n * KT * H2_OPER + tid * 16;
   const unsigned lds0 = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)smem);
   const unsigned wdst = __builtin_amdgcn_readfirstlane(lds0 + H2_OPER + wave * 1024);
@@ -228,16 +228,28 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_b16_kernel(const NTParams p, c
     }
     dma_w(kt + 1, (kt + 1) & 1);
     __builtin_amdgcn_sched_barrier(0);   // DMA strictly before the A loads (vmcnt is in order)
-    if (!TAIL) load_tile(kt + 2, ra[CS ^ 1]);
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!A16) {
+      // fp32 A (8 registers per row pass): ONE register set.  Tile kt+1 is converted into the free
+      // stage first, then its registers take tile kt+2, which has the whole k-tile of MFMAs to land
+      // (two sets of 32 registers next to the accumulator tile spilled 99 VGPRs into the k-loop)
+      store_tile(kt + 1, nxt, ra[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!TAIL) load_tile(kt + 2, ra[0]);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      if (!TAIL) load_tile(kt + 2, ra[CS ^ 1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     b16_compute(acc, cur, wm, wn, l15, kc);
-    store_tile(kt + 1, nxt, ra[CS]);
-    if (!(PRO == PRO_NONE && A16)) {
-      // interleave the conversion with the 64 MFMAs
+    if constexpr (A16) {
+      store_tile(kt + 1, nxt, ra[CS]);
+      if (PRO != PRO_NONE) {
+        // interleave the conversion with the 64 MFMAs
 #pragma unroll
-      for (int g = 0; g < 32; ++g) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        for (int g = 0; g < 32; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        }
       }
     }
     if (TAIL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -248,7 +260,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_b16_kernel(const NTParams p, c
   dma_w(0, 0);
   __builtin_amdgcn_sched_barrier(0);
   load_tile(0, ra[0]);
-  load_tile(1, ra[1]);
+  if constexpr (A16) load_tile(1, ra[1]);
   if (PRO != PRO_NONE) {
     for (int i = tid; i < KP; i += 512) {
       const bool in = i < p.K;
@@ -258,6 +270,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_b16_kernel(const NTParams p, c
     __syncthreads();
   }
   store_tile(0, smem, ra[0]);
+  if constexpr (!A16) load_tile(1, ra[0]);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   // tile 0 was converted out of set 0 above: iteration kt converts tile kt+1 from set (kt+1)&1

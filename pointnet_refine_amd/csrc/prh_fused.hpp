@@ -303,17 +303,23 @@ __global__ __launch_bounds__(512, 2) void encoder_fused_kernel(const FusedParams
     fe_gemm<NPL, 4>(F[hf], smem, 0, 30, wptr(4, 8) + (size_t)hf * 4 * rbs(4), rbs(4), l15, q);
   // ---- conv5 in four 256-channel chunks, each consumed by the fusion conv at once
   for (int ch = 0; ch < 4; ++ch) {
+    // lane-derived values are laundered per iteration: with them loop-invariant the compiler hoists
+    // every address of the loop body (fragment pointers, LDS offsets, bias pointers: ~100 registers)
+    // out of the loop, on top of the 128 accumulator registers, and spills 60 of them
+    int lv = lane, l15v = l15, qv = q;
+    asm volatile("" : "+v"(lv), "+v"(l15v), "+v"(qv));
     f32x4 a5[2][CB]; fe_zero(a5);
     // chunk ch = row blocks 16 ch .. 16 ch + 15 of conv5; this wave: 2 of them
-    const char* w5 = img + p.L.w[3] + (size_t)(ch * 16 + wave * 2) * (FE_K[3] / 32) * NPL * 1024 + lane * 16;
-    fe_gemm<NPL, 2>(a5, smem, KB_H4, 16, w5, rbs(3), l15, q);
+    const char* w5 = img + p.L.w[3] + (size_t)(ch * 16 + wave * 2) * (FE_K[3] / 32) * NPL * 1024 + lv * 16;
+    fe_gemm<NPL, 2>(a5, smem, KB_H4, 16, w5, rbs(3), l15v, qv);
     if (ch > 0) __syncthreads();                // the previous chunk's fusion reads are done
-    fe_store_act<NPL, 2, true>(a5, smem, KB_H5, wave * 32, biasp(3) + ch * 256, invs[3], l15, q);
+    fe_store_act<NPL, 2, true>(a5, smem, KB_H5, wave * 32, biasp(3) + ch * 256, invs[3], l15v, qv);
     __syncthreads();
+    const char* wf4 = img + p.L.w[4] + (size_t)(wave * 8) * (FE_K[4] / 32) * NPL * 1024 + lv * 16;
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
-      fe_gemm<NPL, 4>(F[hf], smem, KB_H5, 8, wptr(4, 8) + (size_t)hf * 4 * rbs(4) + (size_t)(30 + ch * 8) * NPL * 1024,
-                      rbs(4), l15, q);
+      fe_gemm<NPL, 4>(F[hf], smem, KB_H5, 8, wf4 + (size_t)hf * 4 * rbs(4) + (size_t)(30 + ch * 8) * NPL * 1024,
+                      rbs(4), l15v, qv);
   }
   __syncthreads();
   // ---- gate hidden layer u = relu(i w1 + b1) into k-blocks 0..1 (h1 is dead)
