@@ -150,11 +150,25 @@ __device__ __forceinline__ void fe_put4(char* p, float a, float b, float c, floa
   }
 }
 
+// the weight fragments of k-step 0 of a GEMM, issued by the caller BEFORE the previous GEMM runs:
+// every layer boundary (epilogue, barrier) otherwise exposes one L2 round trip, 26 times per tile
+template <int NPL, int R> struct FeW { f16x8 w[R][NPL]; };
+template <int NPL, int R>
+__device__ __forceinline__ FeW<NPL, R> fe_first(const char* wimg, size_t rbs) {
+  FeW<NPL, R> f;
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) f.w[r][pl] = *reinterpret_cast<const f16x8*>(wimg + r * rbs + (size_t)pl * 1024);
+  return f;
+}
+
 // acc[R][CB] += W(this wave's R row blocks) H(lds k-blocks kb0 .. kb0 + nkb - 1); nkb even.
-// wimg: fragment (row block 0 of the wave, k-step 0, plane 0) + lane * 16; row blocks rbs bytes apart.
+// wimg: fragment (row block 0 of the wave, k-step 0, plane 0) + lane * 16; row blocks rbs bytes apart;
+// first: fe_first(wimg, rbs), loaded ahead.
 template <int NPL, int R>
 __device__ __forceinline__ void fe_gemm(f32x4 (&acc)[R][FE<NPL>::CB], const char* lds, int kb0, int nkb,
-                                        const char* wimg, size_t rbs, int l15, int kc) {
+                                        const char* wimg, size_t rbs, int l15, int kc, const FeW<NPL, R>& first) {
   constexpr int CB = FE<NPL>::CB;
   f16x8 wf[2][R][NPL];
   auto loadw = [&](f16x8 (&w)[R][NPL], int kt) {
@@ -187,7 +201,10 @@ __device__ __forceinline__ void fe_gemm(f32x4 (&acc)[R][FE<NPL>::CB], const char
   // the scheduling barriers keep each k-step's fragment loads inside its own step: hoisted across
   // steps (or across the unrolled calls of a caller) they pile up on top of the 128 accumulator
   // registers and spill them
-  loadw(wf[0], 0);
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) wf[0][r][pl] = first.w[r][pl];
   for (int kt = 0; kt < nkb; kt += 2) {
     loadw(wf[1], kt + 1);
     step(wf[0], kt);
@@ -249,6 +266,8 @@ __global__ __launch_bounds__(512, 2) void encoder_fused_kernel(const FusedParams
   // LDS k-block map: h1 0..1, h2 2..5, h3 6..13, h4 14..29, h5 chunk 30..37
   constexpr int KB_H1 = 0, KB_H2 = 2, KB_H3 = 6, KB_H4 = 14, KB_H5 = 30;
 
+  // every GEMM's first weight fragments are requested before the GEMM in front of it runs
+  FeW<NPL, 1> f2 = fe_first<NPL, 1>(wptr(0, 1), rbs(0));
   // ---- conv1 + bn1 + relu on the VALU (K = C): item = (point, group of 8 channels)
   {
     const float* w1 = reinterpret_cast<const float*>(img + p.L.c1w);
@@ -275,21 +294,25 @@ __global__ __launch_bounds__(512, 2) void encoder_fused_kernel(const FusedParams
   }
   __syncthreads();
   // ---- conv2..4: every wave computes 1/8 of the output channels for all MT points
+  FeW<NPL, 2> f3 = fe_first<NPL, 2>(wptr(1, 2), rbs(1));
   {
     f32x4 a2[1][CB]; fe_zero(a2);
-    fe_gemm<NPL, 1>(a2, smem, KB_H1, 2, wptr(0, 1), rbs(0), l15, q);
+    fe_gemm<NPL, 1>(a2, smem, KB_H1, 2, wptr(0, 1), rbs(0), l15, q, f2);
     fe_store_act<NPL, 1, true>(a2, smem, KB_H2, wave * 16, biasp(0), invs[0], l15, q);
   }
   __syncthreads();
+  FeW<NPL, 4> f4 = fe_first<NPL, 4>(wptr(2, 4), rbs(2));
   {
     f32x4 a3[2][CB]; fe_zero(a3);
-    fe_gemm<NPL, 2>(a3, smem, KB_H2, 4, wptr(1, 2), rbs(1), l15, q);
+    fe_gemm<NPL, 2>(a3, smem, KB_H2, 4, wptr(1, 2), rbs(1), l15, q, f3);
     fe_store_act<NPL, 2, true>(a3, smem, KB_H3, wave * 32, biasp(1), invs[1], l15, q);
   }
   __syncthreads();
+  const char* wfus = wptr(4, 8);
+  FeW<NPL, 4> ff = fe_first<NPL, 4>(wfus, rbs(4));
   {
     f32x4 a4[4][CB]; fe_zero(a4);
-    fe_gemm<NPL, 4>(a4, smem, KB_H3, 8, wptr(2, 4), rbs(2), l15, q);
+    fe_gemm<NPL, 4>(a4, smem, KB_H3, 8, wptr(2, 4), rbs(2), l15, q, f4);
     fe_store_act<NPL, 4, true>(a4, smem, KB_H4, wave * 64, biasp(2), invs[2], l15, q);
   }
   __syncthreads();
@@ -298,28 +321,39 @@ __global__ __launch_bounds__(512, 2) void encoder_fused_kernel(const FusedParams
   // does not fit next to the 128 accumulator registers; the activation fragments are re-read)
   f32x4 F[2][4][CB];
   fe_zero(F[0]); fe_zero(F[1]);
-#pragma unroll
-  for (int hf = 0; hf < 2; ++hf)
-    fe_gemm<NPL, 4>(F[hf], smem, 0, 30, wptr(4, 8) + (size_t)hf * 4 * rbs(4), rbs(4), l15, q);
+  {
+    FeW<NPL, 4> fn = fe_first<NPL, 4>(wfus + 4 * rbs(4), rbs(4));
+    fe_gemm<NPL, 4>(F[0], smem, 0, 30, wfus, rbs(4), l15, q, ff);
+    ff = fn;
+  }
+  const size_t w5rb = (size_t)(FE_K[3] / 32) * NPL * 1024;
+  const char* w5base = img + p.L.w[3] + (size_t)(wave * 2) * w5rb + lane * 16;
+  FeW<NPL, 2> f5 = fe_first<NPL, 2>(w5base, rbs(3));
+  fe_gemm<NPL, 4>(F[1], smem, 0, 30, wfus + 4 * rbs(4), rbs(4), l15, q, ff);
   // ---- conv5 in four 256-channel chunks, each consumed by the fusion conv at once
+  const char* wgate = wptr(5, 8);
+  FeW<NPL, 1> fg = fe_first<NPL, 1>(wgate, rbs(5));      // gate row block 0: needed after the loop
   for (int ch = 0; ch < 4; ++ch) {
     // lane-derived values are laundered per iteration: with them loop-invariant the compiler hoists
     // every address of the loop body (fragment pointers, LDS offsets, bias pointers: ~100 registers)
     // out of the loop, on top of the 128 accumulator registers, and spills 60 of them
     int lv = lane, l15v = l15, qv = q;
     asm volatile("" : "+v"(lv), "+v"(l15v), "+v"(qv));
+    const char* wf4 = img + p.L.w[4] + (size_t)(wave * 8) * (FE_K[4] / 32) * NPL * 1024 + lv * 16 +
+                      (size_t)(30 + ch * 8) * NPL * 1024;
     f32x4 a5[2][CB]; fe_zero(a5);
     // chunk ch = row blocks 16 ch .. 16 ch + 15 of conv5; this wave: 2 of them
-    const char* w5 = img + p.L.w[3] + (size_t)(ch * 16 + wave * 2) * (FE_K[3] / 32) * NPL * 1024 + lv * 16;
-    fe_gemm<NPL, 2>(a5, smem, KB_H4, 16, w5, rbs(3), l15v, qv);
+    const char* w5 = img + p.L.w[3] + (size_t)(ch * 16 + wave * 2) * w5rb + lv * 16;
+    FeW<NPL, 4> fa = fe_first<NPL, 4>(wf4, rbs(4));
+    fe_gemm<NPL, 2>(a5, smem, KB_H4, 16, w5, rbs(3), l15v, qv, f5);
     if (ch > 0) __syncthreads();                // the previous chunk's fusion reads are done
     fe_store_act<NPL, 2, true>(a5, smem, KB_H5, wave * 32, biasp(3) + ch * 256, invs[3], l15v, qv);
     __syncthreads();
-    const char* wf4 = img + p.L.w[4] + (size_t)(wave * 8) * (FE_K[4] / 32) * NPL * 1024 + lv * 16;
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
-      fe_gemm<NPL, 4>(F[hf], smem, KB_H5, 8, wf4 + (size_t)hf * 4 * rbs(4) + (size_t)(30 + ch * 8) * NPL * 1024,
-                      rbs(4), l15v, qv);
+    FeW<NPL, 4> fb = fe_first<NPL, 4>(wf4 + 4 * rbs(4), rbs(4));
+    fe_gemm<NPL, 4>(F[0], smem, KB_H5, 8, wf4, rbs(4), l15v, qv, fa);
+    // next chunk's conv5 fragments (the last iteration re-reads chunk 3's: harmless)
+    f5 = fe_first<NPL, 2>(img + p.L.w[3] + (size_t)((ch < 3 ? ch + 1 : 3) * 16 + wave * 2) * w5rb + lv * 16, rbs(3));
+    fe_gemm<NPL, 4>(F[1], smem, KB_H5, 8, wf4 + 4 * rbs(4), rbs(4), l15v, qv, fb);
   }
   __syncthreads();
   // ---- gate hidden layer u = relu(i w1 + b1) into k-blocks 0..1 (h1 is dead)
@@ -339,16 +373,18 @@ __global__ __launch_bounds__(512, 2) void encoder_fused_kernel(const FusedParams
   }
   __syncthreads();
   // ---- gate GEMM (K = 64) row block by row block, combine, pooling partials, optional store
+  FeW<NPL, 2> fp = fe_first<NPL, 2>(wptr(6, 2), rbs(6));     // context_proj, for after the gate
   {
     const float* bf = biasp(4) + wave * 128;
     const float* bg = biasp(5) + wave * 128;
     const float sf = invs[4], sg = invs[5];
-    const char* wg = wptr(5, 8);
     float* pw = p.pool_ws != nullptr ? p.pool_ws + (size_t)blockIdx.x * 2048 + wave * 128 : nullptr;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       f32x4 g1[1][CB]; fe_zero(g1);
-      fe_gemm<NPL, 1>(g1, smem, 0, 2, wg + (size_t)r * rbs(5), rbs(5), l15, q);
+      FeW<NPL, 1> fgn = fe_first<NPL, 1>(wgate + (size_t)(r < 7 ? r + 1 : 7) * rbs(5), rbs(5));
+      fe_gemm<NPL, 1>(g1, smem, 0, 2, wgate + (size_t)r * rbs(5), rbs(5), l15, q, fg);
+      fg = fgn;
       const int n = r * 16 + 4 * q;
       const float4 b4 = *reinterpret_cast<const float4*>(bf + n), c4 = *reinterpret_cast<const float4*>(bg + n);
       const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, cc[4] = {c4.x, c4.y, c4.z, c4.w};
@@ -392,7 +428,7 @@ __global__ __launch_bounds__(512, 2) void encoder_fused_kernel(const FusedParams
   __syncthreads();
   {
     f32x4 am[2][CB]; fe_zero(am);
-    fe_gemm<NPL, 2>(am, smem, 0, 32, wptr(6, 2), rbs(6), l15, q);
+    fe_gemm<NPL, 2>(am, smem, 0, 32, wptr(6, 2), rbs(6), l15, q, fp);
     const float sp = invs[6];
     const float* bp = biasp(6) + wave * 32;
 #pragma unroll
