@@ -153,6 +153,26 @@ int prh_linear_backward_bf16(const uint16_t* x, long ldx, const float* w, const 
                              float* db, int rows, int k, int n, void* workspace, size_t workspace_bytes, int device,
                              void* stream);
 
+/* bf16 mode, decoder side: the cross-attention key / value projections of all six layers
+ * (src/model.py:123-126) write their [rows, 6*256] outputs in bf16 and receive bf16 gradients.
+ *   prh_linear_forward_out16: y bf16 [rows,n] = x W^T + b from an fp32 x;
+ *   prh_linear_backward_dy16: dy bf16 -> dx fp32 [rows,k], dw [n,k], db [n] (any may be NULL);
+ *   workspace: prh_linear_bf16_workspace_bytes(rows, k, n, backward).
+ *   prh_attn_forward_kv16 / prh_attn_backward_kv16: prh_attn_forward / prh_attn_backward with K, V
+ *   (and dK, dV) in bf16 storage - leading dimensions in elements, multiples of 8. */
+int prh_linear_forward_out16(const float* x, long ldx, const float* w, const float* b, uint16_t* y, int rows, int k,
+                             int n, void* workspace, size_t workspace_bytes, int device, void* stream);
+int prh_linear_backward_dy16(const float* x, long ldx, const float* w, const uint16_t* dy, float* dx, float* dw,
+                             float* db, int rows, int k, int n, void* workspace, size_t workspace_bytes, int device,
+                             void* stream);
+int prh_attn_forward_kv16(const float* q, long ldq, const uint16_t* k, long ldk, const uint16_t* v, long ldv, float* o,
+                          long ldo, float* lse, int B, int M, int N, int H, float scale, float dropout_p,
+                          unsigned seed, int device, void* stream);
+int prh_attn_backward_kv16(const float* q, long ldq, const uint16_t* k, long ldk, const uint16_t* v, long ldv,
+                           const float* o, long ldo, const float* lse, const float* dout, long lddo, float* dq,
+                           long lddq, uint16_t* dk, long lddk, uint16_t* dv, long lddv, int B, int M, int N, int H,
+                           float scale, float dropout_p, unsigned seed, int device, void* stream);
+
 /* ---- fused EVAL-mode encoder (src/model.py:39-62 with every BatchNorm in eval mode, + :147,194)
  * One kernel takes context [B,N,C] to memory [B,N,256] = context_proj(fused) - and, optionally,
  * fused [B,N,1024] and global_feat [B,2048] - with BatchNorm folded into the conv weights: a

@@ -61,6 +61,7 @@ EXPORTS = [
     "prh_encoder_workspace_bytes", "prh_encoder_forward", "prh_encoder_backward",
     "prh_encoder_bf16_workspace_bytes", "prh_encoder_forward_bf16", "prh_encoder_backward_bf16",
     "prh_linear_bf16_workspace_bytes", "prh_linear_forward_bf16", "prh_linear_backward_bf16",
+    "prh_linear_forward_out16", "prh_linear_backward_dy16", "prh_attn_forward_kv16", "prh_attn_backward_kv16",
     "prh_encoder_fused_image_bytes", "prh_encoder_fused_prepare", "prh_encoder_fused_workspace_bytes",
     "prh_encoder_fused_forward",
     "prh_linear_forward_workspace_bytes", "prh_linear_forward", "prh_linear_forward_ex",
@@ -133,6 +134,15 @@ def _bind(lib):
     lib.prh_linear_forward_bf16.argtypes = [vp, lg, vp, vp, vp, i, i, i, i, vp, sz, i, vp]
     lib.prh_linear_backward_bf16.restype = i
     lib.prh_linear_backward_bf16.argtypes = [vp, lg, vp, vp, vp, vp, vp, i, i, i, vp, sz, i, vp]
+    lib.prh_linear_forward_out16.restype = i
+    lib.prh_linear_forward_out16.argtypes = [vp, lg, vp, vp, vp, i, i, i, vp, sz, i, vp]
+    lib.prh_linear_backward_dy16.restype = i
+    lib.prh_linear_backward_dy16.argtypes = [vp, lg, vp, vp, vp, vp, vp, i, i, i, vp, sz, i, vp]
+    lib.prh_attn_forward_kv16.restype = i
+    lib.prh_attn_forward_kv16.argtypes = [vp, lg, vp, lg, vp, lg, vp, lg, vp, i, i, i, i, f, f, C.c_uint, i, vp]
+    lib.prh_attn_backward_kv16.restype = i
+    lib.prh_attn_backward_kv16.argtypes = [vp, lg, vp, lg, vp, lg, vp, lg, vp, vp, lg, vp, lg, vp, lg, vp, lg,
+                                           i, i, i, i, f, f, C.c_uint, i, vp]
     lib.prh_encoder_fused_image_bytes.restype = sz
     lib.prh_encoder_fused_image_bytes.argtypes = [i, i]
     lib.prh_encoder_fused_prepare.restype = i

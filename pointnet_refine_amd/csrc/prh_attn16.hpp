@@ -54,9 +54,21 @@ __device__ __forceinline__ float a16_scale_acc(const f32x16& x) {
   return pow2_scale(m);
 }
 // 8 floats (times S) -> fragment plane(s)
-template <int PREC>
-__device__ __forceinline__ void a16_split(const float* x_, typename A16<PREC>::frag (&o)[A16<PREC>::NPL], float S = 1.f) {
-  if constexpr (PREC == 0) {
+// (NP = 1 with PREC 0: the values are known to fit one fp16 plane exactly - bf16-stored K / V)
+template <int PREC, int NP>
+__device__ __forceinline__ void a16_split(const float* x_, typename A16<PREC>::frag (&o)[NP], float S = 1.f) {
+  if constexpr (PREC == 0 && NP == 1) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    uint4 h;
+    unsigned* hp = reinterpret_cast<unsigned*>(&h);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v2f v = {x_[2 * j] * S, x_[2 * j + 1] * S};
+      f16x2 hb = __builtin_convertvector(v, f16x2);
+      hp[j] = __builtin_bit_cast(unsigned, hb);
+    }
+    o[0] = __builtin_bit_cast(f16x8, h);
+  } else if constexpr (PREC == 0) {
     float x[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) x[j] = x_[j] * S;
@@ -71,12 +83,12 @@ __device__ __forceinline__ void a16_split(const float* x_, typename A16<PREC>::f
     o[0] = __builtin_bit_cast(bf16x8, h);
   }
 }
-template <int PREC>
-__device__ __forceinline__ f32x16 a16_mma(const typename A16<PREC>::frag (&a)[A16<PREC>::NPL],
-                                          const typename A16<PREC>::frag (&b)[A16<PREC>::NPL], f32x16 c) {
+template <int PREC, int NA, int NB>
+__device__ __forceinline__ f32x16 a16_mma(const typename A16<PREC>::frag (&a)[NA],
+                                          const typename A16<PREC>::frag (&b)[NB], f32x16 c) {
   if constexpr (PREC == 0) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], c, 0, 0, 0);
+    if constexpr (NA > 1) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[NA - 1], b[0], c, 0, 0, 0);
+    if constexpr (NB > 1) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[NB - 1], c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], c, 0, 0, 0);
   } else {
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
@@ -97,13 +109,32 @@ __device__ __forceinline__ void a16_load_rows(const float* base, long ld, long r
       x[s * 8 + 4 * j] = t.x; x[s * 8 + 4 * j + 1] = t.y; x[s * 8 + 4 * j + 2] = t.z; x[s * 8 + 4 * j + 3] = t.w;
     }
 }
+// K / V rows from fp32 or (KV16) bf16 storage: bf16 values are exact in one fp16 plane once placed by
+// the tile's power-of-two scale (8 significant bits of 11), so only the bytes change
+template <bool KV16>
+__device__ __forceinline__ void a16_load_kv(const float* base, long ld, long row0, int rows_valid, int col0,
+                                            int lane, float (&x)[16]) {
+  if constexpr (!KV16) {
+    a16_load_rows(base, ld, row0, rows_valid, col0, lane, x);
+  } else {
+    const int r = lane & 31, h2 = lane >> 5;
+    const bool ok = r < rows_valid;
+    const unsigned short* p = reinterpret_cast<const unsigned short*>(base) + (size_t)(row0 + (ok ? r : 0)) * ld + col0 + h2 * 8;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const uint4 u = ok ? *reinterpret_cast<const uint4*>(p + s * 16) : make_uint4(0u, 0u, 0u, 0u);
+      x[s * 8 + 0] = bf16_lo(u.x); x[s * 8 + 1] = bf16_hi(u.x); x[s * 8 + 2] = bf16_lo(u.y); x[s * 8 + 3] = bf16_hi(u.y);
+      x[s * 8 + 4] = bf16_lo(u.z); x[s * 8 + 5] = bf16_hi(u.z); x[s * 8 + 6] = bf16_lo(u.w); x[s * 8 + 7] = bf16_hi(u.w);
+    }
+  }
+}
 // the lane's row (16 channels as above) -> 16-bit row-major image plane(s): row r, channel c at r*ROWB + 2c
-template <int PREC>
-__device__ __forceinline__ void a16_store_rows(char* img, int lane, const typename A16<PREC>::frag (&f0)[A16<PREC>::NPL],
-                                               const typename A16<PREC>::frag (&f1)[A16<PREC>::NPL]) {
+template <int PREC, int NP>
+__device__ __forceinline__ void a16_store_rows(char* img, int lane, const typename A16<PREC>::frag (&f0)[NP],
+                                               const typename A16<PREC>::frag (&f1)[NP]) {
   const int r = lane & 31, h2 = lane >> 5;
 #pragma unroll
-  for (int pl = 0; pl < A16<PREC>::NPL; ++pl) {
+  for (int pl = 0; pl < NP; ++pl) {
     char* q = img + pl * A16_IMG + r * A16_ROWB + h2 * 16;
     *reinterpret_cast<uint4*>(q) = __builtin_bit_cast(uint4, f0[pl]);
     *reinterpret_cast<uint4*>(q + 32) = __builtin_bit_cast(uint4, f1[pl]);
@@ -114,12 +145,12 @@ __device__ __forceinline__ void a16_store_rows(char* img, int lane, const typena
 }
 // A operand = the TRANSPOSE of a row-major image: lane (column c = l & 31, half h) receives rows
 // 16s + 4h + {0..3} and 16s + 8 + 4h + {0..3} of column c - the rows an accumulator fragment holds
-template <int PREC>
-__device__ __forceinline__ void a16_tr(const char* img, int s, int lane, typename A16<PREC>::frag (&o)[A16<PREC>::NPL]) {
+template <int PREC, int NP>
+__device__ __forceinline__ void a16_tr(const char* img, int s, int lane, typename A16<PREC>::frag (&o)[NP]) {
   const int g = lane >> 4, j = lane & 15;
   const char* a = img + (16 * s + 4 * (g >> 1) + (j >> 2)) * A16_ROWB + (16 * (g & 1) + 4 * (j & 3)) * 2;
 #pragma unroll
-  for (int pl = 0; pl < A16<PREC>::NPL; ++pl) {
+  for (int pl = 0; pl < NP; ++pl) {
     const fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(a + pl * A16_IMG));
     const fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
         (__attribute__((address_space(3))) fp16x4*)(a + pl * A16_IMG + 8 * A16_ROWB));
@@ -128,8 +159,8 @@ __device__ __forceinline__ void a16_tr(const char* img, int s, int lane, typenam
   }
 }
 // registers 8s..8s+7 of an accumulator tile -> B-operand fragment plane(s)
-template <int PREC>
-__device__ __forceinline__ void a16_acc_frag(const f32x16& x, int s, typename A16<PREC>::frag (&o)[A16<PREC>::NPL],
+template <int PREC, int NP>
+__device__ __forceinline__ void a16_acc_frag(const f32x16& x, int s, typename A16<PREC>::frag (&o)[NP],
                                              float S = 1.f) {
   float t[8];
 #pragma unroll
@@ -146,10 +177,11 @@ __device__ __forceinline__ f32x16 a16_zero() {
 // ---------------------------------------------------------------------------------------
 // forward.  LDS per wave: the V tile image (NPL planes).
 // ---------------------------------------------------------------------------------------
-template <int PREC>
+template <int PREC, bool KV16 = false>
 __global__ __launch_bounds__(256) void attn16_fwd_kernel(const AttnParams p) {
   using frag = typename A16<PREC>::frag;
   constexpr int NPL = A16<PREC>::NPL;
+  constexpr int NKV = KV16 ? 1 : NPL;      // bf16-stored K / V are exact in one fp16 plane
   __shared__ __attribute__((aligned(16))) char smem[4 * NPL * A16_IMG];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h2 = lane >> 5, l31 = lane & 31;
@@ -177,16 +209,16 @@ __global__ __launch_bounds__(256) void attn16_fwd_kernel(const AttnParams p) {
     float m_run = -INFINITY, l_run = 0.f;
 
     float kn[16], vn[16];
-    a16_load_rows(p.k, p.ldk, (long)b * p.N, p.N, col0, lane, kn);
-    a16_load_rows(p.v, p.ldv, (long)b * p.N, p.N, col0, lane, vn);
+    a16_load_kv<KV16>(p.k, p.ldk, (long)b * p.N, p.N, col0, lane, kn);
+    a16_load_kv<KV16>(p.v, p.ldv, (long)b * p.N, p.N, col0, lane, vn);
     for (int k0 = 0; k0 < p.N; k0 += 32) {
-      frag kf[2][NPL], vf[2][NPL];
+      frag kf[2][NKV], vf[2][NKV];
       const float sk = a16_scale<PREC>(kn), sv = a16_scale<PREC>(vn);
       a16_split<PREC>(kn, kf[0], sk); a16_split<PREC>(kn + 8, kf[1], sk);
       a16_split<PREC>(vn, vf[0], sv); a16_split<PREC>(vn + 8, vf[1], sv);
       if (k0 + 32 < p.N) {
-        a16_load_rows(p.k, p.ldk, (long)b * p.N + k0 + 32, p.N - k0 - 32, col0, lane, kn);
-        a16_load_rows(p.v, p.ldv, (long)b * p.N + k0 + 32, p.N - k0 - 32, col0, lane, vn);
+        a16_load_kv<KV16>(p.k, p.ldk, (long)b * p.N + k0 + 32, p.N - k0 - 32, col0, lane, kn);
+        a16_load_kv<KV16>(p.v, p.ldv, (long)b * p.N + k0 + 32, p.N - k0 - 32, col0, lane, vn);
       }
       a16_store_rows<PREC>(vimg, lane, vf[0], vf[1]);
       // S^T[key][q]: rows = keys in registers, column = query on the lane
@@ -222,7 +254,7 @@ __global__ __launch_bounds__(256) void attn16_fwd_kernel(const AttnParams p) {
       f32x16 ot = a16_zero();
 #pragma unroll
       for (int st = 0; st < 2; ++st) {
-        frag pf[NPL], va[NPL];
+        frag pf[NPL], va[NKV];
         a16_acc_frag<PREC>(s, st, pf);
         a16_tr<PREC>(vimg, st, lane, va);
         ot = a16_mma<PREC>(va, pf, ot);
@@ -247,10 +279,11 @@ __global__ __launch_bounds__(256) void attn16_fwd_kernel(const AttnParams p) {
 // ---------------------------------------------------------------------------------------
 // backward.  LDS per wave: Q, dO, K images (NPL planes each) + one fp32 transpose scratch.
 // ---------------------------------------------------------------------------------------
-template <int PREC>
+template <int PREC, bool KV16 = false>
 __global__ __launch_bounds__(256) void attn16_bwd_kernel(const AttnParams p) {
   using frag = typename A16<PREC>::frag;
   constexpr int NPL = A16<PREC>::NPL;
+  constexpr int NKV = KV16 ? 1 : NPL;
   constexpr int WAVE_LDS = 3 * NPL * A16_IMG + AT_TILE * 4;
   extern __shared__ __attribute__((aligned(16))) char dsm16[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -299,16 +332,16 @@ __global__ __launch_bounds__(256) void attn16_bwd_kernel(const AttnParams p) {
     for (int r = 0; r < 16; ++r) dqacc[r] = 0.f;
 
     float kn[16], vn[16];
-    a16_load_rows(p.k, p.ldk, (long)b * p.N, p.N, col0, lane, kn);
-    a16_load_rows(p.v, p.ldv, (long)b * p.N, p.N, col0, lane, vn);
+    a16_load_kv<KV16>(p.k, p.ldk, (long)b * p.N, p.N, col0, lane, kn);
+    a16_load_kv<KV16>(p.v, p.ldv, (long)b * p.N, p.N, col0, lane, vn);
     for (int k0 = 0; k0 < p.N; k0 += 32) {
-      frag kf[2][NPL], vf[2][NPL];
+      frag kf[2][NKV], vf[2][NKV];
       const float sk = a16_scale<PREC>(kn), sv = a16_scale<PREC>(vn);
       a16_split<PREC>(kn, kf[0], sk); a16_split<PREC>(kn + 8, kf[1], sk);
       a16_split<PREC>(vn, vf[0], sv); a16_split<PREC>(vn + 8, vf[1], sv);
       if (k0 + 32 < p.N) {
-        a16_load_rows(p.k, p.ldk, (long)b * p.N + k0 + 32, p.N - k0 - 32, col0, lane, kn);
-        a16_load_rows(p.v, p.ldv, (long)b * p.N + k0 + 32, p.N - k0 - 32, col0, lane, vn);
+        a16_load_kv<KV16>(p.k, p.ldk, (long)b * p.N + k0 + 32, p.N - k0 - 32, col0, lane, kn);
+        a16_load_kv<KV16>(p.v, p.ldv, (long)b * p.N + k0 + 32, p.N - k0 - 32, col0, lane, vn);
       }
       a16_store_rows<PREC>(kimg, lane, kf[0], kf[1]);
       const bool key_ok = (k0 + l31) < p.N;
@@ -363,12 +396,22 @@ __global__ __launch_bounds__(256) void attn16_bwd_kernel(const AttnParams p) {
           const int key = (lane >> 3) + 8 * it;
           float4 vv = *reinterpret_cast<const float4*>(scr + key * AT_LD + (lane & 7) * 4);
           if (k0 + key < p.N) {
-            float* gp = dst + (size_t)((long)b * p.N + k0 + key) * ldd + col0 + (lane & 7) * 4;
-            if (qt > 0) {
-              const float4 old = ldg4(gp);
-              vv.x += old.x; vv.y += old.y; vv.z += old.z; vv.w += old.w;
+            const size_t eo = (size_t)((long)b * p.N + k0 + key) * ldd + col0 + (lane & 7) * 4;
+            if constexpr (KV16) {        // gradient arena in bf16 (bf16 mode)
+              uint2* gp = reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(dst) + eo);
+              if (qt > 0) {
+                const uint2 old = *gp;
+                vv.x += bf16_lo(old.x); vv.y += bf16_hi(old.x); vv.z += bf16_lo(old.y); vv.w += bf16_hi(old.y);
+              }
+              *gp = make_uint2(pack_bf16x2(vv.x, vv.y), pack_bf16x2(vv.z, vv.w));
+            } else {
+              float* gp = dst + eo;
+              if (qt > 0) {
+                const float4 old = ldg4(gp);
+                vv.x += old.x; vv.y += old.y; vv.z += old.z; vv.w += old.w;
+              }
+              *reinterpret_cast<float4*>(gp) = vv;
             }
-            *reinterpret_cast<float4*>(gp) = vv;
             const float m4 = fmaxf(fmaxf(fabsf(vv.x), fabsf(vv.y)), fmaxf(fabsf(vv.z), fabsf(vv.w)));
             if (pass == 0) mx_dv = fmaxf(mx_dv, m4); else mx_dk = fmaxf(mx_dk, m4);
           }
@@ -395,7 +438,7 @@ __global__ __launch_bounds__(256) void attn16_bwd_kernel(const AttnParams p) {
         f32x16 dqt = a16_zero();
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
-          frag dsf[NPL], at[NPL];
+          frag dsf[NPL], at[NKV];
           a16_acc_frag<PREC>(dp, st, dsf, sdt);
           a16_tr<PREC>(kimg, st, lane, at);
           dqt = a16_mma<PREC>(at, dsf, dqt);

@@ -137,6 +137,7 @@ bool g_tn_tr = [] { const char* e = getenv("PRH_TN_TR"); return !(e && strcmp(e,
 // Attention cores: 16-bit MFMA (two fp16 planes / three products with the fp32-accurate GEMM modes,
 // one bf16 plane in the bf16 modes); PRH_ATTN=fp32 or GEMM mode 0 keep the exact fp32 MFMA kernels
 bool g_attn_fp32 = [] { const char* e = getenv("PRH_ATTN"); return e && strcmp(e, "fp32") == 0; }();
+thread_local bool g_attn_kv16 = false;      // set by the *_kv16 entry points around the shared launch code
 bool g_attn_bf16 = [] { const char* e = getenv("PRH_ATTN"); return e && strcmp(e, "bf16") == 0; }();
 // -1: exact fp32 MFMA kernels (GEMM mode 0, PRH_ATTN=fp32); 0: two fp16 planes, three products - every
 // other mode, the bf16 modes included: at B=4096 one bf16 plane saves 12 ms of a 300 ms step and
@@ -972,7 +973,7 @@ void lin16_carve(Arena& a, Lin16WS& w, int rows, int k, int n, bool backward) {
   w.wT = a.f((size_t)k * n);
   w.slab = a.f(tn16_slab_floats(rows, n, k));
   w.cslab = a.f(tn16_colsum_floats(rows, n, k));
-  w.dy16 = (u16*)a.f(((size_t)rows * n + 1) / 2);
+  w.dy16 = (u16*)a.f(((size_t)rows * (n > k ? n : k) + 1) / 2);      // dy cast, or (dy16 entry) the x cast
 }
 }  // namespace
 
@@ -1780,6 +1781,47 @@ int prh_linear_backward_bf16(const uint16_t* x, long ldx, const float* w, const 
   return PRH_OK;
 }
 
+// nn.Linear from an fp32 input to a bf16 OUTPUT, and its backward from a bf16 gradient: the wide
+// cross-attention key / value projections of the bf16 mode (src/model.py:123-126 for all six layers),
+// whose outputs and gradients live in bf16
+int prh_linear_forward_out16(const float* x, long ldx, const float* w, const float* b, uint16_t* y, int rows, int k,
+                             int n, void* workspace, size_t workspace_bytes, int device, void* stream) {
+  if (!x || !w || !y || rows < 0 || k <= 0 || n <= 0) return fail(PRH_ERR_ARG, "linear_forward_out16: bad argument");
+  HIP_TRY(hipSetDevice(device));
+  Arena a(workspace, workspace_bytes); Lin16WS lw;
+  lin16_carve(a, lw, rows, k, n, false);
+  if (!a.ok) return fail(PRH_ERR_WORKSPACE, "linear_forward_out16: workspace too small (%zu bytes)", workspace_bytes);
+  NTParams p; memset(&p, 0, sizeof(p));
+  p.A = x; p.lda = ldx; p.W = w; p.ldw = k; p.C = f16p(y); p.ldc = n; p.M = rows; p.N = n; p.K = k; p.bias = b;
+  p.wprep = lw.wprep;
+  return launch_nt_b16<PRO_NONE, EPI_BIAS, false, true>(p, (hipStream_t)stream);
+}
+int prh_linear_backward_dy16(const float* x, long ldx, const float* w, const uint16_t* dy, float* dx, float* dw,
+                             float* db, int rows, int k, int n, void* workspace, size_t workspace_bytes, int device,
+                             void* stream) {
+  if (!x || !w || !dy || rows < 0 || k <= 0 || n <= 0) return fail(PRH_ERR_ARG, "linear_backward_dy16: bad argument");
+  if ((k & 7) || (n & 7)) return fail(PRH_ERR_ARG, "linear_backward_dy16: k=%d and n=%d must be multiples of 8", k, n);
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  Arena a(workspace, workspace_bytes); Lin16WS lw;
+  lin16_carve(a, lw, rows, k, n, true);
+  if (!a.ok) return fail(PRH_ERR_WORKSPACE, "linear_backward_dy16: workspace too small (%zu bytes)", workspace_bytes);
+  if (dx != nullptr) {
+    TRY(transpose(w, n, k, lw.wT, st));   // wT [k, n]
+    NTParams p; memset(&p, 0, sizeof(p));
+    p.A = f16p(dy); p.lda = n; p.W = lw.wT; p.ldw = n; p.C = dx; p.ldc = k; p.M = rows; p.N = k; p.K = n;
+    p.wprep = lw.wprep;
+    TRY((launch_nt_b16<PRO_NONE, EPI_BIAS, true, false>(p, st)));
+  }
+  if (dw != nullptr || db != nullptr) {
+    TRY(cast_b16(x, ldx, k, lw.dy16, k, k, (size_t)rows, st));      // x in bf16: the wgrad's B operand
+    TNParams t; memset(&t, 0, sizeof(t));
+    t.A = f16p(dy); t.lda = n; t.B = f16p(lw.dy16); t.ldb = k; t.P = rows; t.Mo = n; t.Ni = k;
+    TRY((launch_tn_b16<PRO_NONE>(t, lw.slab, lw.cslab, dw, (long)k, db, st)));
+  }
+  return PRH_OK;
+}
+
 // ------------------------------------------------------------------ fused eval encoder (prh_fused.hpp)
 size_t prh_encoder_fused_image_bytes(int planes, int in_channel) {
   if ((planes != 1 && planes != 2) || in_channel < 4 || in_channel > 64) return 0;
@@ -2077,7 +2119,12 @@ int prh_attn_forward(const float* q, long ldq, const float* k, long ldk, const f
                4.0 * B * H * (double)M * N * 32, 4.0 * (2.0 * B * N * H * 32 + 2.0 * B * M * H * 32), st);
   const int wpb = (long)B * (H / 4) < 512 ? 1 : 4;      // one head per workgroup while the grid would not fill the chip
   const int prec = attn_prec();
-  if (prec == 0)
+  if (g_attn_kv16 && prec < 0) return fail(PRH_ERR_ARG, "attention: bf16 K/V need the 16-bit attention cores");
+  if (prec == 0 && g_attn_kv16)
+    hipLaunchKernelGGL((attn16_fwd_kernel<0, true>), dim3((unsigned)(B * (H / wpb))), dim3(64 * wpb), 0, st, a);
+  else if (prec == 1 && g_attn_kv16)
+    hipLaunchKernelGGL((attn16_fwd_kernel<1, true>), dim3((unsigned)(B * (H / wpb))), dim3(64 * wpb), 0, st, a);
+  else if (prec == 0)
     hipLaunchKernelGGL(attn16_fwd_kernel<0>, dim3((unsigned)(B * (H / wpb))), dim3(64 * wpb), 0, st, a);
   else if (prec == 1)
     hipLaunchKernelGGL(attn16_fwd_kernel<1>, dim3((unsigned)(B * (H / wpb))), dim3(64 * wpb), 0, st, a);
@@ -2117,8 +2164,21 @@ int prh_attn_backward_ex(const float* q, long ldq, const float* k, long ldk, con
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess) ? 0 : 1;
     }();
     if (attr16) return fail(PRH_ERR_HIP, "attention_backward: cannot raise the dynamic LDS limit");
-    ProfScope ps(prec == 0 ? "attn16_bwd<split>" : "attn16_bwd<bf16>", 14.0 * B * H * (double)M * N * 32, 4.0 * (4.0 * B * N * H * 32 + 4.0 * B * M * H * 32), st);
-    if (prec == 0)
+    static const int attr16k = [] {
+      return (hipFuncSetAttribute(reinterpret_cast<const void*>(attn16_bwd_kernel<0, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+              hipFuncSetAttribute(reinterpret_cast<const void*>(attn16_bwd_kernel<1, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess) ? 0 : 1;
+    }();
+    if (attr16k) return fail(PRH_ERR_HIP, "attention_backward: cannot raise the dynamic LDS limit");
+    const double kvb = g_attn_kv16 ? 2.0 : 4.0;
+    ProfScope ps(prec == 0 ? "attn16_bwd<split>" : "attn16_bwd<bf16>", 14.0 * B * H * (double)M * N * 32,
+                 kvb * 4.0 * B * N * H * 32 + 4.0 * 4.0 * B * M * H * 32, st);
+    if (prec == 0 && g_attn_kv16)
+      hipLaunchKernelGGL((attn16_bwd_kernel<0, true>), dim3((unsigned)(B * (H / wpb))), dim3(64 * wpb), lds16, st, a);
+    else if (g_attn_kv16)
+      hipLaunchKernelGGL((attn16_bwd_kernel<1, true>), dim3((unsigned)(B * (H / wpb))), dim3(64 * wpb), lds16, st, a);
+    else if (prec == 0)
       hipLaunchKernelGGL(attn16_bwd_kernel<0>, dim3((unsigned)(B * (H / wpb))), dim3(64 * wpb), lds16, st, a);
     else
       hipLaunchKernelGGL(attn16_bwd_kernel<1>, dim3((unsigned)(B * (H / wpb))), dim3(64 * wpb), lds16, st, a);
@@ -2135,6 +2195,31 @@ int prh_attn_backward_ex(const float* q, long ldq, const float* k, long ldk, con
   hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(B * (H / wpb))), dim3(64 * wpb), lds, st, a);
   LAUNCH_CHECK();
   return PRH_OK;
+}
+/* K / V (and dK / dV) in bf16 storage: bf16 mode's wide projection buffers (uint16_t = raw bf16 bits) */
+int prh_attn_forward_kv16(const float* q, long ldq, const uint16_t* k, long ldk, const uint16_t* v, long ldv, float* o,
+                          long ldo, float* lse, int B, int M, int N, int H, float scale, float dropout_p,
+                          unsigned seed, int device, void* stream) {
+  if ((ldk | ldv) & 7) return fail(PRH_ERR_ARG, "attention (bf16 K/V): leading dimensions must be multiples of 8");
+  g_attn_kv16 = true;
+  const int rc = prh_attn_forward(q, ldq, reinterpret_cast<const float*>(k), ldk, reinterpret_cast<const float*>(v), ldv, o,
+                                  ldo, lse, B, M, N, H, scale, dropout_p, seed, device, stream);
+  g_attn_kv16 = false;
+  return rc;
+}
+int prh_attn_backward_kv16(const float* q, long ldq, const uint16_t* k, long ldk, const uint16_t* v, long ldv,
+                           const float* o, long ldo, const float* lse, const float* dout, long lddo, float* dq,
+                           long lddq, uint16_t* dk, long lddk, uint16_t* dv, long lddv, int B, int M, int N, int H,
+                           float scale, float dropout_p, unsigned seed, int device, void* stream) {
+  if ((ldk | ldv | lddk | lddv) & 7) return fail(PRH_ERR_ARG, "attention (bf16 K/V): leading dimensions must be multiples of 8");
+  if (attn_prec() < 0) return fail(PRH_ERR_ARG, "attention: bf16 K/V need the 16-bit attention cores");
+  g_attn_kv16 = true;
+  const int rc = prh_attn_backward_ex(q, ldq, reinterpret_cast<const float*>(k), ldk, reinterpret_cast<const float*>(v), ldv,
+                                      o, ldo, lse, dout, lddo, dq, lddq, reinterpret_cast<float*>(dk), lddk,
+                                      reinterpret_cast<float*>(dv), lddv, B, M, N, H, scale, dropout_p, seed, nullptr,
+                                      device, stream);
+  g_attn_kv16 = false;
+  return rc;
 }
 int prh_attn_backward(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv,
                       const float* o, long ldo, const float* lse, const float* dout, long lddo,

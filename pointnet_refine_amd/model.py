@@ -305,8 +305,13 @@ class LineRefineNet(nn.Module):
         bk = torch.cat([l.cross_attn.in_proj_bias[d:2 * d] for l in layers])
         wv = torch.cat([l.cross_attn.in_proj_weight[2 * d:] for l in layers])
         bv = torch.cat([l.cross_attn.in_proj_bias[2 * d:] for l in layers])
-        k_all = ops.linear(mempos, wk, bk)                          # (B, N, 6*256)
-        v_all = ops.linear(memory, wv, bv)
+        if ops.bf16_mode() and mempos.is_cuda:
+            # bf16 mode (BASELINE config 3): the wide K / V buffers and their gradients live in bf16
+            k_all = ops.linear_out16(mempos, wk, bk)                # (B, N, 6*256) bf16
+            v_all = ops.linear_out16(memory, wv, bv)
+        else:
+            k_all = ops.linear(mempos, wk, bk)                      # (B, N, 6*256)
+            v_all = ops.linear(memory, wv, bv)
         fused = k_all.is_cuda and d == 256
         if fused:
             # the fused attention kernels read column block i of k_all / v_all in place and

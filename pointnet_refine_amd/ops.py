@@ -29,6 +29,11 @@ def _ws(device: torch.device, nbytes: int) -> torch.Tensor:
     return t
 
 
+def bf16_mode() -> bool:
+    """True in GEMM mode 4 (bf16 operands and bf16 activation storage, BASELINE config 3)."""
+    return L.lib().prh_get_gemm_mode() == 4
+
+
 def release_workspaces():
     _workspaces.clear()
 
@@ -199,6 +204,52 @@ class LinearFn(torch.autograd.Function):
 
 def linear(x, w, b=None, x_amax=None, relu=False, resid=None):
     return LinearFn.apply(x, w, b, x_amax, relu, resid)
+
+
+class LinearOut16Fn(torch.autograd.Function):
+    """y (bf16) = x W^T + b from an fp32 x, with a bf16 gradient coming back: the wide cross-attention
+    key / value projections of the bf16 mode (src/model.py:123-126 for all six layers at once)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _req_gpu_f32(x, "input")
+        _req_gpu_f32(w, "weight")
+        n, k = w.shape
+        if x.shape[-1] != k or k % 8 or n % 8:
+            raise RuntimeError("pointnet_refine_amd.linear_out16: in/out features must be multiples of 8")
+        x2 = x.reshape(-1, k)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        w = w.contiguous()
+        rows = x2.shape[0]
+        y = torch.empty((rows, n), dtype=torch.bfloat16, device=x.device)
+        ws = _ws(x.device, L.lib().prh_linear_bf16_workspace_bytes(rows, k, n, 0))
+        L.check(L.lib().prh_linear_forward_out16(_p(x2), k, _p(w), _p(b), _p(y), rows, k, n, _p(ws), ws.numel(),
+                                                 x.device.index, _stream(x.device)), "prh_linear_forward_out16")
+        ctx.save_for_backward(x2, w)
+        ctx.has_bias, ctx.xshape = b is not None, x.shape
+        return y.reshape(*x.shape[:-1], n)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        n, k = w.shape
+        rows, dev = x2.shape[0], x2.device
+        dy2 = dy.reshape(rows, n)
+        if dy2.dtype != torch.bfloat16 or not dy2.is_contiguous():
+            dy2 = dy2.to(torch.bfloat16).contiguous()
+        need_dx, need_dw, need_db = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        dx = torch.empty_like(x2) if need_dx else None
+        dw = torch.empty_like(w) if need_dw else None
+        db = torch.empty(n, dtype=torch.float32, device=dev) if need_db else None
+        ws = _ws(dev, L.lib().prh_linear_bf16_workspace_bytes(rows, k, n, 1))
+        L.check(L.lib().prh_linear_backward_dy16(_p(x2), k, _p(w), _p(dy2), _p(dx), _p(dw), _p(db), rows, k, n, _p(ws),
+                                                 ws.numel(), dev.index, _stream(dev)), "prh_linear_backward_dy16")
+        return (dx.reshape(ctx.xshape) if need_dx else None), dw, db
+
+
+def linear_out16(x, w, b=None):
+    return LinearOut16Fn.apply(x, w, b)
 
 
 class PosHiddenFn(torch.autograd.Function):
@@ -722,16 +773,16 @@ class KVTokenFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, k_all, v_all, arena, block):
         ctx.arena, ctx.block = arena, block
-        ctx.shape, ctx.dev = tuple(k_all.shape), k_all.device
-        return k_all.new_zeros(())
+        ctx.shape, ctx.dev, ctx.dtype = tuple(k_all.shape), k_all.device, k_all.dtype
+        return torch.zeros((), dtype=torch.float32, device=k_all.device)
 
     @staticmethod
     def backward(ctx, dtoken):
         a = ctx.arena
         nblk = ctx.shape[-1] // ctx.block
         if a.dk is None:
-            a.dk = torch.zeros(ctx.shape, dtype=torch.float32, device=ctx.dev)
-            a.dv = torch.zeros(ctx.shape, dtype=torch.float32, device=ctx.dev)
+            a.dk = torch.zeros(ctx.shape, dtype=ctx.dtype, device=ctx.dev)
+            a.dv = torch.zeros(ctx.shape, dtype=ctx.dtype, device=ctx.dev)
         else:
             for i in range(nblk):
                 if i not in a.written:
@@ -743,6 +794,7 @@ class KVTokenFn(torch.autograd.Function):
             # LinearFn.backward through the gradient tensors' addresses (one reduction of the
             # per-wave maxima instead of a read pass over each gradient buffer)
             mx = a.part.amax(dim=(0, 1))
+            _DY_AMAX.clear()      # at most this call's two hints are ever live (popped by their consumers)
             _DY_AMAX[dv.data_ptr()] = (mx[0:1], tuple(dv.shape))
             _DY_AMAX[dk.data_ptr()] = (mx[1:2], tuple(dk.shape))
         a.dk = a.dv = a.part = None
@@ -758,8 +810,13 @@ class AttentionFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, heads, dropout_p, seed, token=None, arena=None, block=0):
         _req_gpu_f32(q, "query")
-        _req_gpu_f32(k, "key")
-        _req_gpu_f32(v, "value")
+        kv16 = k.dtype == torch.bfloat16
+        if kv16:
+            if v.dtype != torch.bfloat16 or not (k.is_cuda and v.is_cuda) or arena is None:
+                raise RuntimeError("pointnet_refine_amd.attention: bf16 K/V come as the wide projection buffers (arena mode)")
+        else:
+            _req_gpu_f32(k, "key")
+            _req_gpu_f32(v, "value")
         B, M, Cq = q.shape
         N = k.shape[1]
         if Cq != heads * 32 or heads % 4:
@@ -779,12 +836,15 @@ class AttentionFn(torch.autograd.Function):
         o = torch.empty_like(q)
         lse = torch.empty((B, heads, M), dtype=torch.float32, device=q.device)
         scale = 1.0 / (32.0 ** 0.5)
-        kp = C.c_void_p(k.data_ptr() + 4 * koff)
-        vp = C.c_void_p(v.data_ptr() + 4 * voff)
-        L.check(L.lib().prh_attn_forward(_p(q), Cq, kp, ldk, vp, ldv, _p(o), Cq, _p(lse), B, M, N,
-                                         heads, scale, float(dropout_p), int(seed) & 0xFFFFFFFF,
-                                         q.device.index, _stream(q.device)), "prh_attn_forward")
+        es = k.element_size()
+        kp = C.c_void_p(k.data_ptr() + es * koff)
+        vp = C.c_void_p(v.data_ptr() + es * voff)
+        fwd = L.lib().prh_attn_forward_kv16 if kv16 else L.lib().prh_attn_forward
+        L.check(fwd(_p(q), Cq, kp, ldk, vp, ldv, _p(o), Cq, _p(lse), B, M, N,
+                    heads, scale, float(dropout_p), int(seed) & 0xFFFFFFFF,
+                    q.device.index, _stream(q.device)), "prh_attn_forward")
         ctx.save_for_backward(q, k, v, o, lse)
+        ctx.kv16 = kv16
         ctx.cfg = (heads, float(dropout_p), int(seed) & 0xFFFFFFFF, scale, ldk, ldv, koff, voff)
         ctx.arena, ctx.block = arena, block
         return o
@@ -803,24 +863,34 @@ class AttentionFn(torch.autograd.Function):
                 a.dk = torch.empty_like(k)
                 a.dv = torch.empty_like(v)
             dk, dv, lddk = a.dk, a.dv, k.shape[2]
-            dkp = C.c_void_p(dk.data_ptr() + 4 * koff)
-            dvp = C.c_void_p(dv.data_ptr() + 4 * voff)
+            es = k.element_size()
+            dkp = C.c_void_p(dk.data_ptr() + es * koff)
+            dvp = C.c_void_p(dv.data_ptr() + es * voff)
             a.written.add(ctx.block)
             nblk, waves = k.shape[2] // Cq, B * (heads // 4) * 4
-            if a.part is None:
-                a.part = torch.zeros((nblk, waves, 2), dtype=torch.float32, device=q.device)
-            partp = C.c_void_p(a.part.data_ptr() + 4 * ctx.block * waves * 2)
+            partp = None
+            if not ctx.kv16:          # operand maxima for the split-fp16 backward GEMMs (not used in the bf16 mode)
+                if a.part is None:
+                    a.part = torch.zeros((nblk, waves, 2), dtype=torch.float32, device=q.device)
+                partp = C.c_void_p(a.part.data_ptr() + 4 * ctx.block * waves * 2)
         else:
             dk = torch.empty((B, N, Cq), dtype=torch.float32, device=q.device)
             dv = torch.empty((B, N, Cq), dtype=torch.float32, device=q.device)
             lddk, dkp, dvp = Cq, _p(dk), _p(dv)
             partp = None
-        kp = C.c_void_p(k.data_ptr() + 4 * koff)
-        vp = C.c_void_p(v.data_ptr() + 4 * voff)
-        L.check(L.lib().prh_attn_backward_ex(_p(q), Cq, kp, ldk, vp, ldv, _p(o), Cq, _p(lse), _p(do), Cq,
-                                             _p(dq), Cq, dkp, lddk, dvp, lddk, B, M, N, heads, scale,
-                                             dropout_p, seed, partp, q.device.index, _stream(q.device)),
-                "prh_attn_backward")
+        es = k.element_size()
+        kp = C.c_void_p(k.data_ptr() + es * koff)
+        vp = C.c_void_p(v.data_ptr() + es * voff)
+        if ctx.kv16:
+            L.check(L.lib().prh_attn_backward_kv16(_p(q), Cq, kp, ldk, vp, ldv, _p(o), Cq, _p(lse), _p(do), Cq,
+                                                   _p(dq), Cq, dkp, lddk, dvp, lddk, B, M, N, heads, scale,
+                                                   dropout_p, seed, q.device.index, _stream(q.device)),
+                    "prh_attn_backward_kv16")
+        else:
+            L.check(L.lib().prh_attn_backward_ex(_p(q), Cq, kp, ldk, vp, ldv, _p(o), Cq, _p(lse), _p(do), Cq,
+                                                 _p(dq), Cq, dkp, lddk, dvp, lddk, B, M, N, heads, scale,
+                                                 dropout_p, seed, partp, q.device.index, _stream(q.device)),
+                    "prh_attn_backward")
         if a is not None:
             return dq, None, None, None, None, None, torch.zeros((), device=q.device), None, None
         return dq, dk, dv, None, None, None, None, None, None
