@@ -277,14 +277,14 @@ __global__ __launch_bounds__(256) void attn16_fwd_kernel(const AttnParams p) {
 }
 
 // ---------------------------------------------------------------------------------------
-// backward.  LDS per wave: Q, dO, K images (NPL planes each) + one fp32 transpose scratch.
+// backward.  LDS per wave: Q, dO, K, dS images (NPL planes each) + one fp32 transpose scratch.
 // ---------------------------------------------------------------------------------------
 template <int PREC, bool KV16 = false>
 __global__ __launch_bounds__(256) void attn16_bwd_kernel(const AttnParams p) {
   using frag = typename A16<PREC>::frag;
   constexpr int NPL = A16<PREC>::NPL;
   constexpr int NKV = KV16 ? 1 : NPL;
-  constexpr int WAVE_LDS = 3 * NPL * A16_IMG + AT_TILE * 4;
+  constexpr int WAVE_LDS = 4 * NPL * A16_IMG + AT_TILE * 4;
   extern __shared__ __attribute__((aligned(16))) char dsm16[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h2 = lane >> 5, l31 = lane & 31;
@@ -295,7 +295,8 @@ __global__ __launch_bounds__(256) void attn16_bwd_kernel(const AttnParams p) {
   char* qimg = dsm16 + wave * WAVE_LDS;
   char* doimg = qimg + NPL * A16_IMG;
   char* kimg = doimg + NPL * A16_IMG;
-  float* scr = reinterpret_cast<float*>(kimg + NPL * A16_IMG);
+  char* dsimg = kimg + NPL * A16_IMG;
+  float* scr = reinterpret_cast<float*>(dsimg + NPL * A16_IMG);
   const int col0 = h * 32;
   const unsigned bh = (unsigned)(b * p.H + h);
   float mx_dv = 0.f, mx_dk = 0.f;
@@ -377,7 +378,16 @@ __global__ __launch_bounds__(256) void attn16_bwd_kernel(const AttnParams p) {
         a16_acc_frag<PREC>(dp, st, dsf, sds);
         a16_tr<PREC>(qimg, st, lane, at);
         dkt = a16_mma<PREC>(at, dsf, dkt);
+        // row `key` of the dS image: elements j = 0..3 are queries 16 st + 4 h2 + j, j = 4..7 are 8 further
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+          const uint4 u = __builtin_bit_cast(uint4, dsf[pl]);
+          char* q = dsimg + pl * A16_IMG + l31 * A16_ROWB + (16 * st + 4 * h2) * 2;
+          *reinterpret_cast<uint2*>(q) = make_uint2(u.x, u.y);
+          *reinterpret_cast<uint2*>(q + 16) = make_uint2(u.z, u.w);
+        }
       }
+      asm volatile("" ::: "memory");
       {
         const float uv = 1.f / sdo, uk = 1.f / (sq * sds);
 #pragma unroll
@@ -417,33 +427,21 @@ __global__ __launch_bounds__(256) void attn16_bwd_kernel(const AttnParams p) {
           }
         }
       }
-      // ---- queries on lanes: S^T[key][q], dP^T[key][q] -> dS^T -> dQ^T += K^T dS^T
-      s = a16_zero(); dp = a16_zero();
-#pragma unroll
-      for (int st = 0; st < 2; ++st) {
-        s = a16_mma<PREC>(kf[st], qf[st], s);
-        dp = a16_mma<PREC>(vf[st], dof[st], dp);
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = k0 + crow(r, h2);
-        const float pr = (key < p.N && qcol < p.M) ? __expf(s[r] * us - lse_col) : 0.f;
-        float keepf = 1.f;
-        if (p.drop_thresh != 0u)
-          keepf = attn_keep(seed_eff, bh, (unsigned)qcol, (unsigned)key, p.drop_thresh) ? p.keep_scale : 0.f;
-        dp[r] = pr * (dp[r] * udp * keepf - dl_col);       // dS^T
-      }
+      // ---- dQ^T[d][q] += K^T dS^T.  dS is in hand with the KEY on the lane; the product wants the
+      // query there.  Its fragments (already split for dK^T) went to a row-major [key][q] image
+      // above; transposed reads of that image and of the K image deliver both operands with the
+      // same key order - no second evaluation of S^T / dP^T (12 MFMAs, 16 exp and 16 dropout
+      // hashes per tile, which is what bound this kernel once the products were cheap)
       {
-        const float sdt = PREC == 0 ? a16_scale_acc(dp) : 1.f;
         f32x16 dqt = a16_zero();
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
-          frag dsf[NPL], at[NKV];
-          a16_acc_frag<PREC>(dp, st, dsf, sdt);
+          frag bt[NPL], at[NKV];
+          a16_tr<PREC>(dsimg, st, lane, bt);
           a16_tr<PREC>(kimg, st, lane, at);
-          dqt = a16_mma<PREC>(at, dsf, dqt);
+          dqt = a16_mma<PREC>(at, bt, dqt);
         }
-        const float uq = 1.f / (sk * sdt);
+        const float uq = 1.f / (sk * sds);
 #pragma unroll
         for (int r = 0; r < 16; ++r) dqacc[r] = fmaf(dqt[r], uq, dqacc[r]);
       }
