@@ -279,12 +279,16 @@ __global__ __launch_bounds__(256) void attn16_fwd_kernel(const AttnParams p) {
 // ---------------------------------------------------------------------------------------
 // backward.  LDS per wave: Q, dO, K, dS images (NPL planes each) + one fp32 transpose scratch.
 // ---------------------------------------------------------------------------------------
+// Two workgroups per CU: 80 KB of LDS each (the fp32 transpose scratch shares the dS image, the
+// per-query scalars sit in the pad bytes of the Q image) and at most 256 registers per wave -
+// the kernel is bound by vector-instruction issue, and one wave alone on a SIMD gets half of it.
 template <int PREC, bool KV16 = false>
-__global__ __launch_bounds__(256) void attn16_bwd_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn16_bwd_kernel(const AttnParams p) {
   using frag = typename A16<PREC>::frag;
   constexpr int NPL = A16<PREC>::NPL;
   constexpr int NKV = KV16 ? 1 : NPL;
-  constexpr int WAVE_LDS = 4 * NPL * A16_IMG + AT_TILE * 4;
+  constexpr bool SCR_IN_DS = AT_TILE * 4 <= NPL * A16_IMG;      // two planes: yes; one bf16 plane: own space
+  constexpr int WAVE_LDS = 4 * NPL * A16_IMG + (SCR_IN_DS ? 0 : AT_TILE * 4);
   extern __shared__ __attribute__((aligned(16))) char dsm16[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h2 = lane >> 5, l31 = lane & 31;
@@ -296,7 +300,7 @@ __global__ __launch_bounds__(256) void attn16_bwd_kernel(const AttnParams p) {
   char* doimg = qimg + NPL * A16_IMG;
   char* kimg = doimg + NPL * A16_IMG;
   char* dsimg = kimg + NPL * A16_IMG;
-  float* scr = reinterpret_cast<float*>(dsimg + NPL * A16_IMG);
+  float* scr = reinterpret_cast<float*>(SCR_IN_DS ? dsimg : dsimg + NPL * A16_IMG);   // the dS image is dead by then
   const int col0 = h * 32;
   const unsigned bh = (unsigned)(b * p.H + h);
   float mx_dv = 0.f, mx_dk = 0.f;
@@ -321,13 +325,10 @@ __global__ __launch_bounds__(256) void attn16_bwd_kernel(const AttnParams p) {
     const int qcol = qt + l31;
     const float lse_col = qcol < p.M ? p.lse[((size_t)b * p.H + h) * p.M + qcol] : 0.f;
     const float dl_col = dl;
-    float lse_row[16], dl_row[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int src = crow(r, h2);
-      lse_row[r] = __shfl(lse_col, src);
-      dl_row[r] = __shfl(dl_col, src);
-    }
+    // per-query scalars in row form (query = crow(r, h2)) are read back from the 16 pad bytes of the Q
+    // image's rows - 32 registers less than keeping them, and a broadcast LDS read each
+    if (h2 == 0) *reinterpret_cast<float2*>(qimg + l31 * A16_ROWB + 64) = make_float2(lse_col, dl_col);
+    asm volatile("" ::: "memory");
     f32x16 dqacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dqacc[r] = 0.f;
@@ -358,11 +359,12 @@ __global__ __launch_bounds__(256) void attn16_bwd_kernel(const AttnParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int q = qt + crow(r, h2);
-        float pr = (key_ok && q < p.M) ? __expf(s[r] * us - lse_row[r]) : 0.f;
+        const float2 qs = *reinterpret_cast<const float2*>(qimg + crow(r, h2) * A16_ROWB + 64);      // (lse, delta) of query q
+        float pr = (key_ok && q < p.M) ? __expf(s[r] * us - qs.x) : 0.f;
         float keepf = 1.f;
         if (p.drop_thresh != 0u)
           keepf = attn_keep(seed_eff, bh, (unsigned)q, (unsigned)(k0 + l31), p.drop_thresh) ? p.keep_scale : 0.f;
-        const float ds = pr * (dp[r] * udp * keepf - dl_row[r]);
+        const float ds = pr * (dp[r] * udp * keepf - qs.y);
         s[r] = pr * keepf;                            // Pd
         dp[r] = ds;                                   // dS
       }
@@ -393,6 +395,25 @@ __global__ __launch_bounds__(256) void attn16_bwd_kernel(const AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dvt[r] *= uv; dkt[r] *= uk; }
       }
+      // ---- dQ^T[d][q] += K^T dS^T.  dS is in hand with the KEY on the lane; the product wants the
+      // query there.  Its fragments (already split for dK^T) went to a row-major [key][q] image
+      // above; transposed reads of that image and of the K image deliver both operands with the
+      // same key order - no second evaluation of S^T / dP^T (12 MFMAs, 16 exp and 16 dropout
+      // hashes per tile, which is what bound this kernel once the products were cheap)
+      {
+        f32x16 dqt = a16_zero();
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          frag bt[NPL], at[NKV];
+          a16_tr<PREC>(dsimg, st, lane, bt);
+          a16_tr<PREC>(kimg, st, lane, at);
+          dqt = a16_mma<PREC>(at, bt, dqt);
+        }
+        const float uq = 1.f / (sk * sds);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dqacc[r] = fmaf(dqt[r], uq, dqacc[r]);
+      }
+      asm volatile("" ::: "memory");      // the scratch below overwrites the dS image
       // transpose through LDS and store rows: lane -> (key = l>>3 + 8*it, 4 floats at (l&7)*4)
 #pragma unroll
       for (int pass = 0; pass < 2; ++pass) {
@@ -426,24 +447,6 @@ __global__ __launch_bounds__(256) void attn16_bwd_kernel(const AttnParams p) {
             if (pass == 0) mx_dv = fmaxf(mx_dv, m4); else mx_dk = fmaxf(mx_dk, m4);
           }
         }
-      }
-      // ---- dQ^T[d][q] += K^T dS^T.  dS is in hand with the KEY on the lane; the product wants the
-      // query there.  Its fragments (already split for dK^T) went to a row-major [key][q] image
-      // above; transposed reads of that image and of the K image deliver both operands with the
-      // same key order - no second evaluation of S^T / dP^T (12 MFMAs, 16 exp and 16 dropout
-      // hashes per tile, which is what bound this kernel once the products were cheap)
-      {
-        f32x16 dqt = a16_zero();
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-          frag bt[NPL], at[NKV];
-          a16_tr<PREC>(dsimg, st, lane, bt);
-          a16_tr<PREC>(kimg, st, lane, at);
-          dqt = a16_mma<PREC>(at, bt, dqt);
-        }
-        const float uq = 1.f / (sk * sds);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dqacc[r] = fmaf(dqt[r], uq, dqacc[r]);
       }
     }
     if (qcol < p.M) {

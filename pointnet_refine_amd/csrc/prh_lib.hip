@@ -2156,7 +2156,7 @@ int prh_attn_backward_ex(const float* q, long ldq, const float* k, long ldk, con
   const int wpb = (long)B * (H / 4) < 512 ? 1 : 4;
   const int prec = attn_prec();
   if (prec >= 0) {
-    const size_t lds16 = (size_t)wpb * (4 * (prec == 0 ? 2 : 1) * A16_IMG + AT_TILE * 4);
+    const size_t lds16 = (size_t)wpb * (4 * (prec == 0 ? 2 : 1) * A16_IMG + (prec == 0 ? 0 : AT_TILE * 4));
     static const int attr16 = [] {
       return (hipFuncSetAttribute(reinterpret_cast<const void*>(attn16_bwd_kernel<0>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
