@@ -615,4 +615,71 @@ __global__ __launch_bounds__(256) void combine_bwd_b16_kernel(
   }
 }
 
+// combine_bwd_b16_kernel with 16-byte accesses: a thread owns 8 consecutive channels of a row
+// (C / 8 threads per row, 256 / (C / 8) rows in flight per block, 64 rows per block = one
+// statistics tile).  C / 8 must be 32, 64, 128 or 256.
+__global__ __launch_bounds__(256) void combine_bwd_b16v_kernel(
+    const unsigned short* dF, const float* __restrict__ d_gfeat, const int32_t* __restrict__ argmax,
+    const unsigned short* __restrict__ zf, unsigned short* gate, const float* __restrict__ s,
+    const float* __restrict__ t, int P, int N, int C, unsigned short* dy_out, float* ws_a, float* ws_b) {
+  __shared__ float red[2][256][8];
+  const int ng = C >> 3;                       // channel groups per row
+  const int cg = threadIdx.x % ng, rl = threadIdx.x / ng, nrl = 256 / ng;
+  const int c0 = cg * 8;
+  const int row0 = blockIdx.x * 64;
+  float sc[8], sh[8], s1[8], s2[8];
+  *reinterpret_cast<float4*>(sc) = ldg4(s + c0); *reinterpret_cast<float4*>(sc + 4) = ldg4(s + c0 + 4);
+  *reinterpret_cast<float4*>(sh) = ldg4(t + c0); *reinterpret_cast<float4*>(sh + 4) = ldg4(t + c0 + 4);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  for (int i = rl; i < 64; i += nrl) {
+    const int row = row0 + i;
+    if (row >= P) break;
+    const size_t off = (size_t)row * C + c0;
+    float d[8], z[8], m[8], dy[8], dg[8];
+    if (dF != nullptr) unpack8(*reinterpret_cast<const uint4*>(dF + off), d);
+    else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d[e] = 0.f;
+    }
+    if (d_gfeat != nullptr) {
+      const int b = row / N, n = row - b * N;
+      const float invn = 1.f / (float)N;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        d[e] += d_gfeat[(size_t)b * 2 * C + C + c0 + e] * invn;
+        if (argmax[(size_t)b * C + c0 + e] == n) d[e] += d_gfeat[(size_t)b * 2 * C + c0 + e];
+      }
+    }
+    unpack8(*reinterpret_cast<const uint4*>(zf + off), z);
+    unpack8(*reinterpret_cast<const uint4*>(gate + off), m);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float pre = fmaf(z[e], sc[e], sh[e]);
+      const float r = fmaxf(pre, 0.f);
+      const float sig = 2.f * m[e] - 1.f;
+      dy[e] = bf16_round(pre > 0.f ? d[e] * m[e] : 0.f);
+      dg[e] = d[e] * r * 0.5f * sig * (1.f - sig);
+      s1[e] += dy[e];
+      s2[e] = fmaf(dy[e], z[e], s2[e]);
+    }
+    *reinterpret_cast<uint4*>(gate + off) = pack8(dg);
+    *reinterpret_cast<uint4*>(dy_out + off) = pack8(dy);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { red[0][threadIdx.x][e] = s1[e]; red[1][threadIdx.x][e] = s2[e]; }
+  __syncthreads();
+  if (rl == 0) {
+    for (int j = 1; j < nrl; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s1[e] += red[0][j * ng + cg][e]; s2[e] += red[1][j * ng + cg][e]; }
+    float* a = ws_a + (size_t)blockIdx.x * C + c0;
+    float* b = ws_b + (size_t)blockIdx.x * C + c0;
+    *reinterpret_cast<float4*>(a) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+    *reinterpret_cast<float4*>(a + 4) = make_float4(s1[4], s1[5], s1[6], s1[7]);
+    *reinterpret_cast<float4*>(b) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+    *reinterpret_cast<float4*>(b + 4) = make_float4(s2[4], s2[5], s2[6], s2[7]);
+  }
+}
+
 }  // namespace prh

@@ -1634,9 +1634,14 @@ int prh_encoder_backward_bf16(const prh_encoder_params* prm, const float* ctx, i
   TRY(copy_cols(prm->conv[0].w, C, C, w.w0pad, c0p, c0p, (size_t)prm->conv[0].cout, st));
 
   // (1) through F = relu(bn(zf)) * m and the pooling: dy_f, dG (over saved.gate), fusion-BN partials
-  hipLaunchKernelGGL(combine_bwd_b16_kernel, dim3(cdiv(P, 64), cdiv(od, 64)), dim3(256), 0, st, (const u16*)d_fused,
-                     d_gfeat, sv->argmax, (const u16*)sv->z_fus, (u16*)sv->gate, sv->bn_scale + cat, sv->bn_shift + cat,
-                     P, N, od, w.dyf, w.ws_a, w.ws_b);
+  if (od == 256 || od == 512 || od == 1024 || od == 2048)      // 16-byte accesses: od / 8 threads per row
+    hipLaunchKernelGGL(combine_bwd_b16v_kernel, dim3(cdiv(P, 64)), dim3(256), 0, st, (const u16*)d_fused, d_gfeat,
+                       sv->argmax, (const u16*)sv->z_fus, (u16*)sv->gate, sv->bn_scale + cat, sv->bn_shift + cat, P, N, od,
+                       w.dyf, w.ws_a, w.ws_b);
+  else
+    hipLaunchKernelGGL(combine_bwd_b16_kernel, dim3(cdiv(P, 64), cdiv(od, 64)), dim3(256), 0, st, (const u16*)d_fused,
+                       d_gfeat, sv->argmax, (const u16*)sv->z_fus, (u16*)sv->gate, sv->bn_scale + cat, sv->bn_shift + cat,
+                       P, N, od, w.dyf, w.ws_a, w.ws_b);
   LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_stage1_kernel, dim3(cdiv(od, 32), BN_SLICES), dim3(256), 0, st, w.ws_a, w.ws_b, cdiv(P, 64),
                      (long)od, od, 64, P, 0, w.stat2);
