@@ -34,6 +34,18 @@ def bf16_mode() -> bool:
     return L.lib().prh_get_gemm_mode() == 4
 
 
+GEMM_MODES = {"fp32": 0, "split": 1, "bf16op": 2, "split16": 3, "bf16": 4}
+
+
+def set_gemm_mode(mode) -> int:
+    """Select the GEMM core family (`prh_set_gemm_mode`): a name of GEMM_MODES or its number.
+    Returns the previous mode."""
+    m = GEMM_MODES[mode] if isinstance(mode, str) else int(mode)
+    old = L.lib().prh_get_gemm_mode()
+    L.check(L.lib().prh_set_gemm_mode(m), "prh_set_gemm_mode")
+    return old
+
+
 def release_workspaces():
     _workspaces.clear()
 
