@@ -20,6 +20,7 @@
 #include "prh_gemm_s3.hpp"
 #include "prh_gemm_h2.hpp"
 #include "prh_b16.hpp"
+#include "prh_small.hpp"
 #include "prh_fused.hpp"
 #include "prh_context.hpp"
 #include "prh_kernels.hpp"
@@ -131,6 +132,8 @@ inline int core_mode() { return gemm_mode() == 4 ? 2 : gemm_mode(); }
 bool g_h2_gen2 = [] { const char* e = getenv("PRH_H2_GEN"); return !(e && strcmp(e, "1") == 0); }();
 // PRH_TN_TR=0 keeps the split-fp16 wgrads on the column-staged core
 int g_tn_skew = [] { const char* e = getenv("PRH_TN_SKEW"); return e ? atoi(e) : 0; }();   // diagnostic
+// PRH_SMALL=0 keeps the launches the small-problem cores (prh_small.hpp) would take on the 128 x 128 fp32 cores
+bool g_small = [] { const char* e = getenv("PRH_SMALL"); return !(e && strcmp(e, "0") == 0); }();
 bool g_tn_pace = [] { const char* e = getenv("PRH_TN_PACE"); return !(e && strcmp(e, "0") == 0); }();
 bool g_tn_tr = [] { const char* e = getenv("PRH_TN_TR"); return !(e && strcmp(e, "0") == 0); }();
 // PRH_POOL_FUSED=0 keeps the dual pooling a separate pass over `fused` (A/B comparison)
@@ -333,6 +336,50 @@ int launch_tn_b16(TNParams& p, float* slab, float* colsum_slab, float* C, long l
   return PRH_OK;
 }
 
+// ------------------------------------------------------------------ small-problem cores
+inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+// launches the 128 x 128 tiling would turn into less than ~3/4 of a round of workgroups
+inline bool small_nt_ok(const NTParams& p, bool nn) {
+  if (!g_small || p.M < 1 || (p.K % SM_BK) != 0 || (p.lda & 3) || (p.ldw & 3) || !al16(p.A) || !al16(p.W)) return false;
+  if ((long)cdiv(p.M, BM) * cdiv(p.N, BN) >= 192) return false;
+  if (nn && (p.N & 31)) return false;
+  return true;
+}
+template <int TM, int TN, int KS, bool NN>
+int launch_small_cfg(NTParams& p, hipStream_t st) {
+  static const int attr = allow_big_lds(gemm_small_kernel<TM, TN, KS, NN>);
+  if (attr != PRH_OK) return attr;
+  p.tiles_n = cdiv(p.N, TN * 32);
+  const long tiles = (long)p.tiles_n * cdiv(p.M, TM * 32);
+  char nm[64];
+  snprintf(nm, sizeof(nm), "gemm_small<%d%d%d,%s> K=%d N=%d", TM, TN, KS, NN ? "nn" : "nt", p.K, p.N);
+  const double by = 4.0 * ((double)p.M * p.K + (double)p.M * p.N * ((p.flags & F_RESID) ? 2 : 1) + (double)p.N * p.K);
+  ProfScope ps(nm, 2.0 * p.M * (double)p.N * p.K, by, st);
+  hipLaunchKernelGGL((gemm_small_kernel<TM, TN, KS, NN>), dim3((unsigned)tiles), dim3(256), (small_lds<TM, TN, KS>()), st, p);
+  LAUNCH_CHECK();
+  return PRH_OK;
+}
+template <bool NN>
+int launch_small(NTParams& p, hipStream_t st) {
+  p.flags &= ~F_POOL;
+  const bool n64 = !NN || (p.N & 63) == 0;
+  if (n64 && (long)cdiv(p.M, 64) * cdiv(p.N, 64) >= 192) return launch_small_cfg<2, 2, 1, NN>(p, st);
+  if (n64 && (long)cdiv(p.M, 32) * cdiv(p.N, 64) >= 192) return launch_small_cfg<1, 2, 2, NN>(p, st);
+  return launch_small_cfg<1, 1, 4, NN>(p, st);
+}
+// wgrad: 64 x 64 tiles, rows split in multiples of 64 until ~2 rounds of workgroups exist
+constexpr int TN_SMALL_MAX_P = 16384;
+inline bool small_tn_dims_ok(int P, int Mo, int Ni) {
+  return g_small && P >= 64 && P <= TN_SMALL_MAX_P && (P & 63) == 0 && (Mo & 63) == 0 && (Ni & 63) == 0;
+}
+inline void small_tn_plan(int P, int Mo, int Ni, int& splits, int& rps) {
+  const int tiles = (Mo / 64) * (Ni / 64), chunks = P / 64;
+  int s = cdiv(512, tiles);
+  s = s > chunks ? chunks : (s < 1 ? 1 : s);
+  rps = cdiv(chunks, s) * 64;
+  splits = cdiv(P, rps);
+}
+
 // ------------------------------------------------------------------ launch helpers
 template <int PRO, int EPI>
 int launch_nt(NTParams& p, hipStream_t st, StatInfo* si = nullptr) {   // p.amaxA is filled in when measured
@@ -423,6 +470,9 @@ int launch_nt(NTParams& p, hipStream_t st, StatInfo* si = nullptr) {   // p.amax
       return PRH_OK;
     }
   }
+  if constexpr (PRO == PRO_NONE && EPI == EPI_BIAS) {
+    if (small_nt_ok(p, false)) return launch_small<false>(p, st);
+  }
   p.tiles_n = cdiv(p.N, BN);
   const long tiles = (long)p.tiles_n * cdiv(p.M, BM);
   snprintf(nm, sizeof(nm), "gemm_nt<%d,%d> K=%d N=%d", PRO, EPI, p.K, p.N);
@@ -476,7 +526,11 @@ inline TNPlan tn_plan(int P, int Mo, int Ni, bool allow_s3, long maxld = TN_S3_M
 constexpr int TN_HDR = S3_HDR_FLOATS;
 inline size_t tn_splits_bound(int P, int Mo, int Ni) {   // over both cores and any leading dimension
   const size_t a = (size_t)tn_plan(P, Mo, Ni, true).splits, b = (size_t)tn_plan(P, Mo, Ni, false).splits;
-  const size_t c = (size_t)tn_plan(P, Mo, Ni, true, 4).splits;
+  size_t c = (size_t)tn_plan(P, Mo, Ni, true, 4).splits;
+  if (small_tn_dims_ok(P, Mo, Ni)) {
+    int ss, rr; small_tn_plan(P, Mo, Ni, ss, rr);
+    if ((size_t)ss > c) c = (size_t)ss;
+  }
   return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 inline size_t tn_slab_floats(int P, int Mo, int Ni) { return tn_splits_bound(P, Mo, Ni) * Mo * Ni + TN_HDR; }
@@ -557,6 +611,19 @@ int launch_tn(TNParams& p, float* slab, float* colsum_slab, float* C, long ldc, 
         else
           hipLaunchKernelGGL((gemm_tn_s3_kernel<PROA, PROB, 3>), dim3((unsigned)blocks), dim3(512),
                              S3_LDS, st, p);
+        done = true;
+      }
+    }
+    if constexpr (PROA == PRO_NONE && PROB == PRO_NONE) {
+      if (!done && small_tn_dims_ok(p.P, p.Mo, p.Ni) && (p.lda & 3) == 0 && (p.ldb & 3) == 0 && al16(p.A) && al16(p.B)) {
+        static const int attr_sm = allow_big_lds(gemm_tn_small_kernel);
+        if (attr_sm != PRH_OK) return attr_sm;
+        small_tn_plan(p.P, p.Mo, p.Ni, pl.splits, pl.rows_per_split);
+        pl.tiles_m = p.Mo / 64; pl.tiles_n = p.Ni / 64;
+        p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n; p.splits = pl.splits; p.rows_per_split = pl.rows_per_split;
+        snprintf(nm, sizeof(nm), "gemm_tn_small Mo=%d Ni=%d", p.Mo, p.Ni);
+        ProfScope ps(nm, 2.0 * p.P * (double)p.Mo * p.Ni, by, st);
+        hipLaunchKernelGGL(gemm_tn_small_kernel, dim3((unsigned)(pl.tiles_m * pl.tiles_n * pl.splits)), dim3(256), 65536, st, p);
         done = true;
       }
     }
@@ -1196,7 +1263,17 @@ int prh_linear_backward_full(const float* x, long ldx, const float* w, const flo
   if (!a.ok) return fail(PRH_ERR_WORKSPACE, "linear_backward: workspace too small (%zu bytes)", workspace_bytes);
   float *wT = lw.wT, *slab = lw.slab, *cslab = lw.cslab;
   const float* dy_amax = dy_amax_in;
-  if (dx != nullptr) {
+  bool dx_done = false;
+  const bool big16 = gemm_mode() == 4 && rows >= g_b16_min_rows && (long)cdiv(rows, 256) * cdiv(k, 256) >= 16;
+  if (dx != nullptr && !big16) {      // small problem: dgrad with the weight as stored (no transposed copy)
+    NTParams p; memset(&p, 0, sizeof(p));
+    p.A = dy; p.lda = n; p.W = w; p.ldw = k; p.C = dx; p.ldc = k; p.M = rows; p.N = k; p.K = n;
+    if (small_nt_ok(p, true) && !(nt_use_s3(rows, k, n))) {
+      TRY((launch_small<true>(p, st)));
+      dx_done = true;
+    }
+  }
+  if (dx != nullptr && !dx_done) {
     TRY(transpose(w, n, k, wT, st));   // wT [k, n]
     NTParams p; memset(&p, 0, sizeof(p));
     p.A = dy; p.lda = n; p.W = wT; p.ldw = n; p.C = dx; p.ldc = k; p.M = rows; p.N = k; p.K = n;

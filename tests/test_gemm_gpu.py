@@ -27,7 +27,10 @@ def lib(request):
 
 @pytest.mark.parametrize("m,n,k", [(128, 128, 32), (1, 4, 4), (257, 64, 64), (1000, 1984, 1024),
                                    (333, 100, 1984), (4096, 1024, 1984), (70, 3, 128), (777, 300, 72),
-                                   (512, 128, 64), (1031, 1984, 1024)])
+                                   (512, 128, 64), (1031, 1984, 1024),
+                                   # small-problem cores (prh_small.hpp): 32x32 / 32x64 / 64x64 tiles
+                                   (1024, 256, 256), (1024, 1024, 256), (1024, 256, 1024), (4096, 256, 256),
+                                   (1000, 100, 128), (33, 256, 64), (1, 8, 64), (3000, 252, 192)])
 def test_gemm_nt(lib, m, n, k):
     g = torch.Generator(device="cuda").manual_seed(m * 7 + n * 3 + k)
     a = torch.randn(m, k, device="cuda", generator=g)
@@ -47,7 +50,10 @@ def test_gemm_nt(lib, m, n, k):
 
 @pytest.mark.parametrize("p,mo,ni", [(32, 128, 128), (1, 4, 4), (1000, 64, 4), (5000, 1024, 1984),
                                      (100000, 128, 64), (777, 256, 1024), (65, 1024, 64), (4099, 300, 260),
-                                     (20000, 1024, 1984)])
+                                     (20000, 1024, 1984),
+                                     # small wgrad core: rows and both widths multiples of 64
+                                     (1024, 256, 256), (1024, 1024, 256), (64, 64, 64), (4096, 128, 1024),
+                                     (1088, 256, 192)])
 def test_gemm_tn(lib, p, mo, ni):
     g = torch.Generator(device="cuda").manual_seed(p + mo + ni)
     a = torch.randn(p, mo, device="cuda", generator=g)
@@ -199,3 +205,34 @@ def test_split16_component_wise_rows_far_below_the_maximum():
     assert e3[20] < 2e-5 and e3[24] < 4e-4, e3
     assert e3[24] > e3[12]                                # the degradation is real, and bounded
     assert max(e1.values()) < 1e-6, e1                    # split-bf16 (3 planes): no range dependence
+
+
+@pytest.mark.parametrize("rows,k,n", [(1024, 256, 256), (1024, 256, 1024), (1024, 1024, 256), (1000, 256, 128),
+                                      (4096, 256, 256), (96, 128, 96)])
+@pytest.mark.parametrize("relu,resid", [(False, False), (True, False), (False, True)])
+def test_small_linear_forward_backward(rows, k, n, relu, resid):
+    """ops.linear on the query-side shapes of the decoder at small batch (prh_small.hpp: NT forward,
+    NN dgrad with the weight as stored, 64 x 64 wgrad) against fp64 torch."""
+    from pointnet_refine_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(rows + k + n)
+    x = torch.randn(rows, k, device="cuda", generator=g, requires_grad=True)
+    w = (torch.randn(n, k, device="cuda", generator=g) / k ** 0.5).requires_grad_()
+    b = torch.randn(n, device="cuda", generator=g, requires_grad=True)
+    r = torch.randn(rows, n, device="cuda", generator=g, requires_grad=True) if resid else None
+    dy = torch.randn(rows, n, device="cuda", generator=g)
+    y = ops.linear(x, w, b, relu=relu, resid=r)
+    y.backward(dy)
+    xd, wd, bd = (t.detach().double().requires_grad_() for t in (x, w, b))
+    rd = r.detach().double().requires_grad_() if resid else None
+    yr = xd @ wd.t() + bd
+    if resid:
+        yr = yr + rd
+    if relu:
+        yr = yr.relu()
+    yr.backward(dy.double())
+    assert maxdiff(y, yr) < 2e-5
+    assert maxdiff(x.grad, xd.grad) < 2e-5
+    assert maxdiff(w.grad, wd.grad) < 2e-5 * rows ** 0.5
+    assert maxdiff(b.grad, bd.grad) < 2e-5 * rows ** 0.5
+    if resid:
+        assert maxdiff(r.grad, rd.grad) < 1e-6
