@@ -51,6 +51,8 @@ struct AttnParams {
                               // operand maxima of the K/V projection's backward GEMMs, for free
   const unsigned* seed_src;   // optional device word mixed into the seed (graph replays: a counter
                               // the caller advances on the device, so every replay draws new masks)
+  int ksplit;                 // 16-bit cores, small batches: > 0 = keys per wave (multiple of 32); the
+                              // waves of a workgroup then share ONE (segment, head) and split its keys
 };
 
 // effective seed of a launch: the host value, mixed with the device word when one is registered

@@ -177,19 +177,31 @@ __device__ __forceinline__ f32x16 a16_zero() {
 // ---------------------------------------------------------------------------------------
 // forward.  LDS per wave: the V tile image (NPL planes).
 // ---------------------------------------------------------------------------------------
+// Key-split mode (p.ksplit > 0; small batches, where B x H waves would leave the chip idle): the
+// workgroup's waves share one (segment, head), each takes p.ksplit keys, and the partial softmax
+// states (running maximum, sum, unnormalised O^T) are merged through LDS once per query tile.
+template <int PREC> constexpr int a16_fwd_wave_lds() {
+  return A16<PREC>::NPL * A16_IMG > 18 * 64 * 4 ? A16<PREC>::NPL * A16_IMG : 18 * 64 * 4;
+}
 template <int PREC, bool KV16 = false>
-__global__ __launch_bounds__(256) void attn16_fwd_kernel(const AttnParams p) {
+__global__ __launch_bounds__(512) void attn16_fwd_kernel(const AttnParams p) {
   using frag = typename A16<PREC>::frag;
   constexpr int NPL = A16<PREC>::NPL;
   constexpr int NKV = KV16 ? 1 : NPL;      // bf16-stored K / V are exact in one fp16 plane
-  __shared__ __attribute__((aligned(16))) char smem[4 * NPL * A16_IMG];
+  constexpr int WL = a16_fwd_wave_lds<PREC>();
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h2 = lane >> 5, l31 = lane & 31;
   const int wpb = blockDim.x >> 6;
   const int hpb = p.H / wpb;
-  const int b = blockIdx.x / hpb, h = (blockIdx.x % hpb) * wpb + wave;
+  const bool split = p.ksplit > 0;
+  const int b = split ? blockIdx.x / p.H : blockIdx.x / hpb;
+  const int h = split ? blockIdx.x % p.H : (blockIdx.x % hpb) * wpb + wave;
+  const int kbeg = split ? wave * p.ksplit : 0;
+  int kend = split ? kbeg + p.ksplit : p.N;
+  kend = kend > p.N ? p.N : kend;
   const unsigned seed_eff = effective_seed(p.seed, p.seed_src);
-  char* vimg = smem + wave * (NPL * A16_IMG);
+  char* vimg = smem + wave * WL;
   const int col0 = h * 32;
   const unsigned bh = (unsigned)(b * p.H + h);
 
@@ -209,14 +221,16 @@ __global__ __launch_bounds__(256) void attn16_fwd_kernel(const AttnParams p) {
     float m_run = -INFINITY, l_run = 0.f;
 
     float kn[16], vn[16];
-    a16_load_kv<KV16>(p.k, p.ldk, (long)b * p.N, p.N, col0, lane, kn);
-    a16_load_kv<KV16>(p.v, p.ldv, (long)b * p.N, p.N, col0, lane, vn);
-    for (int k0 = 0; k0 < p.N; k0 += 32) {
+    if (kbeg < kend) {
+      a16_load_kv<KV16>(p.k, p.ldk, (long)b * p.N + kbeg, p.N - kbeg, col0, lane, kn);
+      a16_load_kv<KV16>(p.v, p.ldv, (long)b * p.N + kbeg, p.N - kbeg, col0, lane, vn);
+    }
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
       frag kf[2][NKV], vf[2][NKV];
       const float sk = a16_scale<PREC>(kn), sv = a16_scale<PREC>(vn);
       a16_split<PREC>(kn, kf[0], sk); a16_split<PREC>(kn + 8, kf[1], sk);
       a16_split<PREC>(vn, vf[0], sv); a16_split<PREC>(vn + 8, vf[1], sv);
-      if (k0 + 32 < p.N) {
+      if (k0 + 32 < kend) {
         a16_load_kv<KV16>(p.k, p.ldk, (long)b * p.N + k0 + 32, p.N - k0 - 32, col0, lane, kn);
         a16_load_kv<KV16>(p.v, p.ldv, (long)b * p.N + k0 + 32, p.N - k0 - 32, col0, lane, vn);
       }
@@ -263,8 +277,41 @@ __global__ __launch_bounds__(256) void attn16_fwd_kernel(const AttnParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[r] = fmaf(ot[r], uv, oacc[r]);
     }
-    const float inv = 1.f / l_run;
     const int q = qt + l31;
+    if (split) {
+      // merge the waves' partial states: each leaves (O^T registers, m, l) in its own image space;
+      // waves 0..3 each finish one group of four channels
+      asm volatile("" ::: "memory");
+      float* part = reinterpret_cast<float*>(vimg);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part[r * 64 + lane] = oacc[r];
+      part[16 * 64 + lane] = m_run;
+      part[17 * 64 + lane] = l_run;
+      __syncthreads();
+      for (int g = wave; g < 4; g += wpb) {
+        float mt = -INFINITY;
+        for (int sw = 0; sw < wpb; ++sw) mt = fmaxf(mt, reinterpret_cast<const float*>(smem + sw * WL)[16 * 64 + lane]);
+        float lt = 0.f;
+        float4 ov = zero4();
+        for (int sw = 0; sw < wpb; ++sw) {
+          const float* ps = reinterpret_cast<const float*>(smem + sw * WL);
+          const float ms = ps[16 * 64 + lane];
+          const float w = ms == -INFINITY ? 0.f : __expf(ms - mt);
+          lt = fmaf(ps[17 * 64 + lane], w, lt);
+          ov.x = fmaf(ps[(4 * g) * 64 + lane], w, ov.x); ov.y = fmaf(ps[(4 * g + 1) * 64 + lane], w, ov.y);
+          ov.z = fmaf(ps[(4 * g + 2) * 64 + lane], w, ov.z); ov.w = fmaf(ps[(4 * g + 3) * 64 + lane], w, ov.w);
+        }
+        const float inv = 1.f / lt;
+        if (q < p.M) {
+          float* op = p.o + (size_t)((long)b * p.M + q) * p.ldo + col0;
+          *reinterpret_cast<float4*>(op + 8 * g + 4 * h2) = make_float4(ov.x * inv, ov.y * inv, ov.z * inv, ov.w * inv);
+          if (g == 0 && h2 == 0) p.lse[((size_t)b * p.H + h) * p.M + q] = mt + __logf(lt);
+        }
+      }
+      __syncthreads();
+      continue;
+    }
+    const float inv = 1.f / l_run;
     if (q < p.M) {
       float* op = p.o + (size_t)((long)b * p.M + q) * p.ldo + col0;
 #pragma unroll
@@ -282,8 +329,10 @@ __global__ __launch_bounds__(256) void attn16_fwd_kernel(const AttnParams p) {
 // Two workgroups per CU: 80 KB of LDS each (the fp32 transpose scratch shares the dS image, the
 // per-query scalars sit in the pad bytes of the Q image) and at most 256 registers per wave -
 // the kernel is bound by vector-instruction issue, and one wave alone on a SIMD gets half of it.
-template <int PREC, bool KV16 = false>
-__global__ __launch_bounds__(256, 2) void attn16_bwd_kernel(const AttnParams p) {
+// Key-split mode as in the forward: dK / dV tiles belong to one wave each, the dQ^T partial sums
+// are added through LDS (up to 8 waves = the whole 160 KB).
+template <int PREC, bool KV16 = false, bool KSPLIT = false>
+__global__ __launch_bounds__(KSPLIT ? 512 : 256, KSPLIT ? 1 : 2) void attn16_bwd_kernel(const AttnParams p) {
   using frag = typename A16<PREC>::frag;
   constexpr int NPL = A16<PREC>::NPL;
   constexpr int NKV = KV16 ? 1 : NPL;
@@ -294,7 +343,12 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_kernel(const AttnParams p) 
   const int h2 = lane >> 5, l31 = lane & 31;
   const int wpb = blockDim.x >> 6;
   const int hpb = p.H / wpb;
-  const int b = blockIdx.x / hpb, h = (blockIdx.x % hpb) * wpb + wave;
+  constexpr bool split = KSPLIT;
+  const int b = split ? blockIdx.x / p.H : blockIdx.x / hpb;
+  const int h = split ? blockIdx.x % p.H : (blockIdx.x % hpb) * wpb + wave;
+  const int kbeg = split ? wave * p.ksplit : 0;
+  int kend = split ? kbeg + p.ksplit : p.N;
+  kend = kend > p.N ? p.N : kend;
   const unsigned seed_eff = effective_seed(p.seed, p.seed_src);
   char* qimg = dsm16 + wave * WAVE_LDS;
   char* doimg = qimg + NPL * A16_IMG;
@@ -334,14 +388,16 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_kernel(const AttnParams p) 
     for (int r = 0; r < 16; ++r) dqacc[r] = 0.f;
 
     float kn[16], vn[16];
-    a16_load_kv<KV16>(p.k, p.ldk, (long)b * p.N, p.N, col0, lane, kn);
-    a16_load_kv<KV16>(p.v, p.ldv, (long)b * p.N, p.N, col0, lane, vn);
-    for (int k0 = 0; k0 < p.N; k0 += 32) {
+    if (kbeg < kend) {
+      a16_load_kv<KV16>(p.k, p.ldk, (long)b * p.N + kbeg, p.N - kbeg, col0, lane, kn);
+      a16_load_kv<KV16>(p.v, p.ldv, (long)b * p.N + kbeg, p.N - kbeg, col0, lane, vn);
+    }
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
       frag kf[2][NKV], vf[2][NKV];
       const float sk = a16_scale<PREC>(kn), sv = a16_scale<PREC>(vn);
       a16_split<PREC>(kn, kf[0], sk); a16_split<PREC>(kn + 8, kf[1], sk);
       a16_split<PREC>(vn, vf[0], sv); a16_split<PREC>(vn + 8, vf[1], sv);
-      if (k0 + 32 < p.N) {
+      if (k0 + 32 < kend) {
         a16_load_kv<KV16>(p.k, p.ldk, (long)b * p.N + k0 + 32, p.N - k0 - 32, col0, lane, kn);
         a16_load_kv<KV16>(p.v, p.ldv, (long)b * p.N + k0 + 32, p.N - k0 - 32, col0, lane, vn);
       }
@@ -449,7 +505,24 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_kernel(const AttnParams p) 
         }
       }
     }
-    if (qcol < p.M) {
+    if (split) {
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int r = 0; r < 16; ++r) scr[r * 64 + lane] = dqacc[r];
+      __syncthreads();
+      for (int g = wave; g < 4 && qcol < p.M; g += wpb) {
+        float4 dv4 = zero4();
+        for (int sw = 0; sw < wpb; ++sw) {
+          const float* ps = reinterpret_cast<const float*>(dsm16 + sw * WAVE_LDS + (scr - reinterpret_cast<float*>(qimg)) * 4);
+          dv4.x += ps[(4 * g) * 64 + lane]; dv4.y += ps[(4 * g + 1) * 64 + lane];
+          dv4.z += ps[(4 * g + 2) * 64 + lane]; dv4.w += ps[(4 * g + 3) * 64 + lane];
+        }
+        float* dqp = p.dq + (size_t)((long)b * p.M + qcol) * p.lddq + col0;
+        *reinterpret_cast<float4*>(dqp + 8 * g + 4 * h2) =
+            make_float4(dv4.x * p.scale, dv4.y * p.scale, dv4.z * p.scale, dv4.w * p.scale);
+      }
+      __syncthreads();
+    } else if (qcol < p.M) {
       float* dqp = p.dq + (size_t)((long)b * p.M + qcol) * p.lddq + col0;
 #pragma unroll
       for (int g = 0; g < 4; ++g)
@@ -464,7 +537,16 @@ __global__ __launch_bounds__(256, 2) void attn16_bwd_kernel(const AttnParams p) 
       mx_dv = fmaxf(mx_dv, __shfl_xor(mx_dv, o));
       mx_dk = fmaxf(mx_dk, __shfl_xor(mx_dk, o));
     }
-    if (lane == 0) {
+    if (split) {     // one pair per workgroup (= per head), as many entries as the other mode writes
+      float* red = reinterpret_cast<float*>(dsm16);
+      if (lane == 0) { red[wave * 2] = mx_dv; red[wave * 2 + 1] = mx_dk; }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        for (int sw = 1; sw < wpb; ++sw) { mx_dv = fmaxf(mx_dv, red[sw * 2]); mx_dk = fmaxf(mx_dk, red[sw * 2 + 1]); }
+        p.kv_amax_part[(size_t)blockIdx.x * 2] = mx_dv;
+        p.kv_amax_part[(size_t)blockIdx.x * 2 + 1] = mx_dk;
+      }
+    } else if (lane == 0) {
       p.kv_amax_part[(size_t)(blockIdx.x * wpb + wave) * 2] = mx_dv;
       p.kv_amax_part[(size_t)(blockIdx.x * wpb + wave) * 2 + 1] = mx_dk;
     }

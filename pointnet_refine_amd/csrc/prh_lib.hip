@@ -262,7 +262,7 @@ inline TNPlan16 tn_plan_b16(int P, int Mo, int Ni, long maxld) {
   TNPlan16 pl;
   pl.tiles_m = cdiv(Mo, 256); pl.tiles_n = cdiv(Ni, 256);
   const int tiles = pl.tiles_m * pl.tiles_n;
-  int s = cdiv(768, tiles);
+  int s = cdiv(P >= 262144 ? 768 : 256, tiles);
   int best = s; double bw = 1e9;       // whole rounds of the 256 CUs (see tn_plan)
   for (int c = (s > 3 ? s - 2 : 1); c <= s + 4; ++c) {
     const double blocks = (double)tiles * c, w = (double)cdiv((long)blocks, 256L) * 256.0 / blocks;
@@ -495,7 +495,9 @@ inline TNPlan tn_plan(int P, int Mo, int Ni, bool allow_s3, long maxld = TN_S3_M
   pl.tiles_m = cdiv(Mo, tile);
   pl.tiles_n = cdiv(Ni, tile);
   const int tiles = pl.tiles_m * pl.tiles_n;
-  int s = cdiv(pl.s3 ? 768 : 1024, tiles);
+  // three rounds of workgroups where the GEMM is long; one where the slab reduction that follows
+  // (splits x Mo x Ni floats) would cost a sizeable part of it (P < 256 k rows)
+  int s = cdiv(pl.s3 ? (P >= 262144 ? 768 : 256) : 1024, tiles);
   if (pl.s3) {
     // one workgroup per CU: the launch runs in rounds of 256 workgroups, so pick the split
     // count near the target whose last round is fullest (33 splits x 32 tiles = 4.1 rounds
@@ -2176,6 +2178,17 @@ int prh_context_build(const float* cloud, int npts, const float* dense, int n_de
 }
 
 // ------------------------------------------------------------------ fused cross-attention
+// PRH_ATTN_KSPLIT=0: never split the keys of a head over the waves of a workgroup (A/B comparison)
+bool g_attn_ksplit = [] { const char* e = getenv("PRH_ATTN_KSPLIT"); return !(e && strcmp(e, "0") == 0); }();
+// small batches (B x H heads would occupy a fraction of the chip's wave slots) with long key
+// ranges: up to eight waves per head, each a multiple of 32 keys
+static bool attn_ksplit(int B, int H, int N, int& keys_per_wave) {
+  keys_per_wave = 0;
+  if (!g_attn_ksplit || (long)B * H > 1024 || N < 128) return false;
+  int nw = cdiv(N, 32) < 8 ? cdiv(N, 32) : 8;
+  keys_per_wave = cdiv(cdiv(N, 32), nw) * 32;
+  return true;
+}
 static int check_attn(const AttnParams& a) {
   if (!a.q || !a.k || !a.v || !a.o || !a.lse || a.B <= 0 || a.M <= 0 || a.N <= 0)
     return fail(PRH_ERR_ARG, "attention: bad argument");
@@ -2199,19 +2212,22 @@ int prh_attn_forward(const float* q, long ldq, const float* k, long ldk, const f
   const int prec_ = attn_prec();
   ProfScope ps(prec_ < 0 ? "attn_fwd" : (prec_ == 0 ? "attn16_fwd<split>" : "attn16_fwd<bf16>"),
                4.0 * B * H * (double)M * N * 32, 4.0 * (2.0 * B * N * H * 32 + 2.0 * B * M * H * 32), st);
-  const int wpb = (long)B * (H / 4) < 512 ? 1 : 4;      // one head per workgroup while the grid would not fill the chip
+  int wpb = (long)B * (H / 4) < 512 ? 1 : 4;      // one head per workgroup while the grid would not fill the chip
   const int prec = attn_prec();
   if (g_attn_kv16 && prec < 0) return fail(PRH_ERR_ARG, "attention: bf16 K/V need the 16-bit attention cores");
+  unsigned grid = (unsigned)(B * (H / wpb));
+  if (prec >= 0 && attn_ksplit(B, H, N, a.ksplit)) { wpb = cdiv(N, a.ksplit); grid = (unsigned)(B * H); }
+  const size_t ldsf = (size_t)wpb * (prec == 0 ? a16_fwd_wave_lds<0>() : a16_fwd_wave_lds<1>());
   if (prec == 0 && g_attn_kv16)
-    hipLaunchKernelGGL((attn16_fwd_kernel<0, true>), dim3((unsigned)(B * (H / wpb))), dim3(64 * wpb), 0, st, a);
+    hipLaunchKernelGGL((attn16_fwd_kernel<0, true>), dim3(grid), dim3(64 * wpb), ldsf, st, a);
   else if (prec == 1 && g_attn_kv16)
-    hipLaunchKernelGGL((attn16_fwd_kernel<1, true>), dim3((unsigned)(B * (H / wpb))), dim3(64 * wpb), 0, st, a);
+    hipLaunchKernelGGL((attn16_fwd_kernel<1, true>), dim3(grid), dim3(64 * wpb), ldsf, st, a);
   else if (prec == 0)
-    hipLaunchKernelGGL(attn16_fwd_kernel<0>, dim3((unsigned)(B * (H / wpb))), dim3(64 * wpb), 0, st, a);
+    hipLaunchKernelGGL(attn16_fwd_kernel<0>, dim3(grid), dim3(64 * wpb), ldsf, st, a);
   else if (prec == 1)
-    hipLaunchKernelGGL(attn16_fwd_kernel<1>, dim3((unsigned)(B * (H / wpb))), dim3(64 * wpb), 0, st, a);
+    hipLaunchKernelGGL(attn16_fwd_kernel<1>, dim3(grid), dim3(64 * wpb), ldsf, st, a);
   else
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(B * (H / wpb))), dim3(64 * wpb), 0, st, a);
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(grid), dim3(64 * wpb), 0, st, a);
   LAUNCH_CHECK();
   return PRH_OK;
 }
@@ -2235,9 +2251,11 @@ int prh_attn_backward_ex(const float* q, long ldq, const float* k, long ldk, con
   if ((lddo | lddq | lddk | lddv) & 3) return fail(PRH_ERR_ARG, "attention_backward: leading dimensions must be multiples of 4");
   HIP_TRY(hipSetDevice(device));
   hipStream_t st = (hipStream_t)stream;
-  const int wpb = (long)B * (H / 4) < 512 ? 1 : 4;
+  int wpb = (long)B * (H / 4) < 512 ? 1 : 4;
   const int prec = attn_prec();
   if (prec >= 0) {
+    unsigned grid = (unsigned)(B * (H / wpb));
+    if (attn_ksplit(B, H, N, a.ksplit)) { wpb = cdiv(N, a.ksplit); grid = (unsigned)(B * H); }
     const size_t lds16 = (size_t)wpb * (4 * (prec == 0 ? 2 : 1) * A16_IMG + (prec == 0 ? 0 : AT_TILE * 4));
     static const int attr16 = [] {
       return (hipFuncSetAttribute(reinterpret_cast<const void*>(attn16_bwd_kernel<0>),
@@ -2256,14 +2274,34 @@ int prh_attn_backward_ex(const float* q, long ldq, const float* k, long ldk, con
     const double kvb = g_attn_kv16 ? 2.0 : 4.0;
     ProfScope ps(prec == 0 ? "attn16_bwd<split>" : "attn16_bwd<bf16>", 14.0 * B * H * (double)M * N * 32,
                  kvb * 4.0 * B * N * H * 32 + 4.0 * 4.0 * B * M * H * 32, st);
-    if (prec == 0 && g_attn_kv16)
-      hipLaunchKernelGGL((attn16_bwd_kernel<0, true>), dim3((unsigned)(B * (H / wpb))), dim3(64 * wpb), lds16, st, a);
+    if (a.ksplit > 0) {
+      static const int attr16s = [] {
+        return (hipFuncSetAttribute(reinterpret_cast<const void*>(attn16_bwd_kernel<0, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                hipFuncSetAttribute(reinterpret_cast<const void*>(attn16_bwd_kernel<1, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                hipFuncSetAttribute(reinterpret_cast<const void*>(attn16_bwd_kernel<0, true, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                hipFuncSetAttribute(reinterpret_cast<const void*>(attn16_bwd_kernel<1, true, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess) ? 0 : 1;
+      }();
+      if (attr16s) return fail(PRH_ERR_HIP, "attention_backward: cannot raise the dynamic LDS limit");
+      if (prec == 0 && g_attn_kv16)
+        hipLaunchKernelGGL((attn16_bwd_kernel<0, true, true>), dim3(grid), dim3(64 * wpb), lds16, st, a);
+      else if (g_attn_kv16)
+        hipLaunchKernelGGL((attn16_bwd_kernel<1, true, true>), dim3(grid), dim3(64 * wpb), lds16, st, a);
+      else if (prec == 0)
+        hipLaunchKernelGGL((attn16_bwd_kernel<0, false, true>), dim3(grid), dim3(64 * wpb), lds16, st, a);
+      else
+        hipLaunchKernelGGL((attn16_bwd_kernel<1, false, true>), dim3(grid), dim3(64 * wpb), lds16, st, a);
+    } else if (prec == 0 && g_attn_kv16)
+      hipLaunchKernelGGL((attn16_bwd_kernel<0, true>), dim3(grid), dim3(64 * wpb), lds16, st, a);
     else if (g_attn_kv16)
-      hipLaunchKernelGGL((attn16_bwd_kernel<1, true>), dim3((unsigned)(B * (H / wpb))), dim3(64 * wpb), lds16, st, a);
+      hipLaunchKernelGGL((attn16_bwd_kernel<1, true>), dim3(grid), dim3(64 * wpb), lds16, st, a);
     else if (prec == 0)
-      hipLaunchKernelGGL(attn16_bwd_kernel<0>, dim3((unsigned)(B * (H / wpb))), dim3(64 * wpb), lds16, st, a);
+      hipLaunchKernelGGL(attn16_bwd_kernel<0>, dim3(grid), dim3(64 * wpb), lds16, st, a);
     else
-      hipLaunchKernelGGL(attn16_bwd_kernel<1>, dim3((unsigned)(B * (H / wpb))), dim3(64 * wpb), lds16, st, a);
+      hipLaunchKernelGGL(attn16_bwd_kernel<1>, dim3(grid), dim3(64 * wpb), lds16, st, a);
     LAUNCH_CHECK();
     return PRH_OK;
   }

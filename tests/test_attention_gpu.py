@@ -25,7 +25,10 @@ def _ref(q, k, v, H, keep=None, p=0.0):
 
 @pytest.mark.parametrize("B,M,N,p", [(3, 32, 64, 0.0), (2, 32, 1000, 0.0), (5, 32, 33, 0.0),
                                      (2, 32, 257, 0.1), (1, 64, 96, 0.25), (3, 20, 70, 0.0),
-                                     (2, 45, 130, 0.2)])
+                                     (2, 45, 130, 0.2),
+                                     # key-split mode (B x H <= 1024, N >= 128): 8 waves per head;
+                                     # and the same key count with too many heads for it
+                                     (32, 32, 2048, 0.1), (130, 32, 256, 0.1)])
 def test_attention_fwd_bwd(B, M, N, p):
     from pointnet_refine_amd import ops
     H, C = 8, 256
