@@ -301,10 +301,11 @@ class LineRefineNet(nn.Module):
         d = self.d_model
         layers = self.decoder_layers
         mempos = self.pos_emb(context[:, :, :3], resid=memory)      # memory + pos_mem, (B, N, 256)
-        wk = torch.cat([l.cross_attn.in_proj_weight[d:2 * d] for l in layers])
-        bk = torch.cat([l.cross_attn.in_proj_bias[d:2 * d] for l in layers])
-        wv = torch.cat([l.cross_attn.in_proj_weight[2 * d:] for l in layers])
-        bv = torch.cat([l.cross_attn.in_proj_bias[2 * d:] for l in layers])
+        cat = ops.cat_rows if memory.is_cuda else torch.cat
+        wk = cat([l.cross_attn.in_proj_weight[d:2 * d] for l in layers])
+        bk = cat([l.cross_attn.in_proj_bias[d:2 * d] for l in layers])
+        wv = cat([l.cross_attn.in_proj_weight[2 * d:] for l in layers])
+        bv = cat([l.cross_attn.in_proj_bias[2 * d:] for l in layers])
         if ops.bf16_mode() and mempos.is_cuda:
             # bf16 mode (BASELINE config 3): the wide K / V buffers and their gradients live in bf16
             k_all = ops.linear_out16(mempos, wk, bk)                # (B, N, 6*256) bf16

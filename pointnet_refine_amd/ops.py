@@ -50,6 +50,139 @@ def release_workspaces():
     _workspaces.clear()
 
 
+# ------------------------------------------------------------------------------------------
+# Gradient sinks.  Autograd adds every parameter gradient a Function returns into the existing
+# `.grad` with one elementwise kernel per parameter (~250 launches per step of this model).  A
+# training loop that owns the gradient buffers (train_step.TrainStep: one flat fp32 buffer, zeroed
+# at the start of a step) registers them here; while `sinks_active` the backward kernels then write
+# a parameter's gradient straight into its buffer - the first contribution of a step overwrites,
+# later ones (decoder micro-batches, shared weights) are added - and the Function returns None for
+# it.  Views of a registered parameter (the q / k / v row blocks of an in_proj_weight) resolve to
+# the matching slice.  Invariant: within a step, a region of the buffer is written either by these
+# Functions or by autograd, never both before the Functions' first write.
+# ------------------------------------------------------------------------------------------
+_GRAD_SINKS = {}          # id(parameter) -> (parameter, gradient tensor)
+_SINK_WRITTEN = set()     # (data_ptr, numel) of the regions written in the current step
+_SINKS_ACTIVE = False
+_DIRECT = object()
+
+
+def register_grad_sinks(params_and_grads):
+    for prm, g in params_and_grads:
+        if g is not None and g.is_contiguous() and g.dtype == torch.float32:
+            _GRAD_SINKS[id(prm)] = (prm, g)
+
+
+def clear_grad_sinks(params=None):
+    if params is None:
+        _GRAD_SINKS.clear()
+    else:
+        for prm in params:
+            _GRAD_SINKS.pop(id(prm), None)
+    _SINK_WRITTEN.clear()
+
+
+class sinks_active:
+    """with ops.sinks_active(new_step=True): forward + backward of one (micro-)batch."""
+
+    def __init__(self, new_step=True):
+        self.new_step = new_step
+
+    def __enter__(self):
+        global _SINKS_ACTIVE
+        self.prev = _SINKS_ACTIVE
+        _SINKS_ACTIVE = bool(_GRAD_SINKS)
+        if self.new_step:
+            _SINK_WRITTEN.clear()
+        return self
+
+    def __exit__(self, *exc):
+        global _SINKS_ACTIVE
+        _SINKS_ACTIVE = self.prev
+        return False
+
+
+class CatRowsFn(torch.autograd.Function):
+    """torch.cat of row blocks of several parameters (the key / value rows of the six in_proj weights,
+    model.py cross-attention projections) whose backward hands every block's gradient to its sink
+    with one copy (first contribution of the step) or add, instead of autograd's zero-padded
+    full-size gradient per slice plus an accumulation each."""
+
+    @staticmethod
+    def forward(ctx, *blocks):
+        ctx.sinks = [_sink_view(b) for b in blocks]
+        ctx.sizes = [b.shape[0] for b in blocks]
+        return torch.cat(blocks)
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, o = [], 0
+        for sink, n in zip(ctx.sinks, ctx.sizes):
+            gi = g[o:o + n]
+            o += n
+            if sink is None or not _SINKS_ACTIVE:
+                outs.append(gi)
+                continue
+            key = (sink.data_ptr(), sink.numel())
+            if key in _SINK_WRITTEN:
+                sink.add_(gi)
+            else:
+                _SINK_WRITTEN.add(key)
+                sink.copy_(gi)
+            outs.append(None)
+        return tuple(outs)
+
+
+def cat_rows(blocks):
+    return CatRowsFn.apply(*blocks)
+
+
+def _sink_view(w):
+    """Forward-time lookup: the gradient region of `w` (a registered parameter or a contiguous view
+    of one), or None."""
+    if not _SINKS_ACTIVE or w is None or not w.requires_grad:
+        return None
+    base = w._base if w._base is not None else w
+    ent = _GRAD_SINKS.get(id(base))
+    if ent is None:
+        return None
+    g = ent[1]
+    if w is base:
+        return g if g.shape == w.shape else None
+    if not w.is_contiguous() or not base.is_contiguous():
+        return None
+    off = w.storage_offset() - base.storage_offset()
+    if off < 0 or off + w.numel() > g.numel():
+        return None
+    return g.reshape(-1)[off:off + w.numel()].view(w.shape)
+
+
+def _grad_buf(sink, shape, dev, need=True):
+    """(fp32 tensor of `shape` the backward kernel writes, token for _grad_ret)."""
+    if not need:
+        return None, None
+    shape = tuple(int(d) for d in shape)
+    n = 1
+    for d in shape:
+        n *= d
+    if sink is None or not _SINKS_ACTIVE or sink.numel() != n:
+        return torch.empty(shape, dtype=torch.float32, device=dev), None
+    sink = sink.view(shape)
+    key = (sink.data_ptr(), sink.numel())
+    if key in _SINK_WRITTEN:
+        return torch.empty(shape, dtype=torch.float32, device=dev), sink
+    _SINK_WRITTEN.add(key)
+    return sink, _DIRECT
+
+
+def _grad_ret(buf, token):
+    if token is None:
+        return buf
+    if token is not _DIRECT:
+        token.add_(buf)
+    return None
+
+
 def _stream(device) -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
@@ -92,6 +225,7 @@ class LinearFn(torch.autograd.Function):
         operand for the split-fp16 core; e.g. the encoder's bound for its output).  relu: apply
         ReLU in the GEMM epilogue (the backward masks dy with y > 0).  resid: tensor of the output's
         shape added in the epilogue, y = act(x W^T + b + resid)."""
+        ctx.w_sink, ctx.b_sink = _sink_view(w), _sink_view(b)
         if x.dtype == torch.bfloat16:
             return LinearFn._forward_bf16(ctx, x, w, b, relu, resid)
         _req_gpu_f32(x, "input")
@@ -170,12 +304,12 @@ class LinearFn(torch.autograd.Function):
         dy2 = dy.reshape(rows, n).float().contiguous()
         need_dx, need_dw, need_db = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         dx = torch.empty_like(x2) if need_dx else None
-        dw = torch.empty_like(w) if need_dw else None
-        db = torch.empty(n, dtype=torch.float32, device=dev) if need_db else None
+        dw, tw = _grad_buf(ctx.w_sink, w.shape, dev, need_dw)
+        db, tb = _grad_buf(ctx.b_sink, (n,), dev, need_db)
         ws = _ws(dev, L.lib().prh_linear_bf16_workspace_bytes(rows, k, n, 1))
         L.check(L.lib().prh_linear_backward_bf16(_p(x2), k, _p(w), _p(dy2), _p(dx), _p(dw), _p(db), rows, k, n, _p(ws),
                                                  ws.numel(), dev.index, _stream(dev)), "prh_linear_backward_bf16")
-        return (dx.reshape(ctx.xshape) if need_dx else None), dw, db, None, None, None
+        return (dx.reshape(ctx.xshape) if need_dx else None), _grad_ret(dw, tw), _grad_ret(db, tb), None, None, None
 
     @staticmethod
     def backward(ctx, dy):
@@ -200,8 +334,8 @@ class LinearFn(torch.autograd.Function):
         dev = x2.device
         need_dx, need_dw, need_db = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         dx = torch.empty_like(x2) if need_dx else None
-        dw = torch.empty_like(w) if need_dw else None
-        db = torch.empty(n, dtype=torch.float32, device=dev) if need_db else None
+        dw, tw = _grad_buf(ctx.w_sink, w.shape, dev, need_dw)
+        db, tb = _grad_buf(ctx.b_sink, (n,), dev, need_db)
         nb = L.lib().prh_linear_backward_workspace_bytes(rows, k, n)
         ws = _ws(dev, nb)
         L.check(L.lib().prh_linear_backward_full(_p(x2), k, _p(w), _p(dy2), _p(dx), _p(dw), _p(db), rows,
@@ -211,7 +345,7 @@ class LinearFn(torch.autograd.Function):
         dres = None
         if ctx.has_resid and ctx.needs_input_grad[5]:
             dres = dy2.reshape(*ctx.xshape[:-1], n)      # (masked by the ReLU when there is one)
-        return (dx.reshape(ctx.xshape) if need_dx else None), dw, db, None, None, dres
+        return (dx.reshape(ctx.xshape) if need_dx else None), _grad_ret(dw, tw), _grad_ret(db, tb), None, None, dres
 
 
 def linear(x, w, b=None, x_amax=None, relu=False, resid=None):
@@ -224,6 +358,7 @@ class LinearOut16Fn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b):
+        ctx.w_sink, ctx.b_sink = _sink_view(w), _sink_view(b)
         _req_gpu_f32(x, "input")
         _req_gpu_f32(w, "weight")
         n, k = w.shape
@@ -252,12 +387,12 @@ class LinearOut16Fn(torch.autograd.Function):
             dy2 = dy2.to(torch.bfloat16).contiguous()
         need_dx, need_dw, need_db = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         dx = torch.empty_like(x2) if need_dx else None
-        dw = torch.empty_like(w) if need_dw else None
-        db = torch.empty(n, dtype=torch.float32, device=dev) if need_db else None
+        dw, tw = _grad_buf(ctx.w_sink, w.shape, dev, need_dw)
+        db, tb = _grad_buf(ctx.b_sink, (n,), dev, need_db)
         ws = _ws(dev, L.lib().prh_linear_bf16_workspace_bytes(rows, k, n, 1))
         L.check(L.lib().prh_linear_backward_dy16(_p(x2), k, _p(w), _p(dy2), _p(dx), _p(dw), _p(db), rows, k, n, _p(ws),
                                                  ws.numel(), dev.index, _stream(dev)), "prh_linear_backward_dy16")
-        return (dx.reshape(ctx.xshape) if need_dx else None), dw, db
+        return (dx.reshape(ctx.xshape) if need_dx else None), _grad_ret(dw, tw), _grad_ret(db, tb)
 
 
 def linear_out16(x, w, b=None):
@@ -272,6 +407,7 @@ class PosHiddenFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xyz, w0, b0):
+        ctx.w_sink, ctx.b_sink = _sink_view(w0), _sink_view(b0)
         _req_gpu_f32(xyz, "input")
         _req_gpu_f32(w0, "weight")
         hdim = w0.shape[0]
@@ -306,14 +442,14 @@ class PosHiddenFn(torch.autograd.Function):
             raise RuntimeError("pos_hidden: gradient with respect to the points is implemented for hidden <= 256")
         need_dw, need_db = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         dx = torch.empty((*xyz.shape[:-1], 3), dtype=torch.float32, device=dev) if need_dx else None
-        dw = torch.empty((hdim, 3), dtype=torch.float32, device=dev) if need_dw else None
-        db = torch.empty(hdim, dtype=torch.float32, device=dev) if need_db else None
+        dw, tw = _grad_buf(ctx.w_sink, (hdim, 3), dev, need_dw)
+        db, tb = _grad_buf(ctx.b_sink, (hdim,), dev, need_db)
         if need_dx or need_dw or need_db:
             ws = _ws(dev, L.lib().prh_pos_hidden_backward_workspace_bytes(rows, hdim))
             L.check(L.lib().prh_pos_hidden_backward(_p(xyz), ctx.ld, _p(h), _p(dh), _p(w0), _p(dx), _p(dw), _p(db),
                                                     rows, hdim, _p(ws), ws.numel(), dev.index, _stream(dev)),
                     "prh_pos_hidden_backward")
-        return dx, dw, db
+        return dx, _grad_ret(dw, tw), _grad_ret(db, tb)
 
 
 class LinearSmallFn(torch.autograd.Function):
@@ -322,6 +458,7 @@ class LinearSmallFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b):
+        ctx.w_sink, ctx.b_sink = _sink_view(w), _sink_view(b)
         _req_gpu_f32(x, "input")
         _req_gpu_f32(w, "weight")
         n, k = w.shape
@@ -348,13 +485,13 @@ class LinearSmallFn(torch.autograd.Function):
         dy2 = dy.reshape(rows, n).contiguous()
         need_dx, need_dw, need_db = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         dx = torch.empty_like(x2) if need_dx else None
-        dw = torch.empty_like(w) if need_dw else None
-        db = torch.empty(n, dtype=torch.float32, device=dev) if need_db else None
+        dw, tw = _grad_buf(ctx.w_sink, w.shape, dev, need_dw)
+        db, tb = _grad_buf(ctx.b_sink, (n,), dev, need_db)
         ws = _ws(dev, L.lib().prh_linear_small_backward_workspace_bytes(rows, k, n))
         L.check(L.lib().prh_linear_small_backward(_p(x2), _p(w), _p(dy2), _p(dx), _p(dw), _p(db), rows, k, n,
                                                   _p(ws), ws.numel(), dev.index, _stream(dev)),
                 "prh_linear_small_backward")
-        return (dx.reshape(ctx.xshape) if need_dx else None), dw, db
+        return (dx.reshape(ctx.xshape) if need_dx else None), _grad_ret(dw, tw), _grad_ret(db, tb)
 
 
 def linear_small(x, w, b=None):
@@ -412,6 +549,7 @@ class MlpStackFn(torch.autograd.Function):
         ctx.save_for_backward(x, z_cat, coef, *ws_, *[params[4 * l + 2] for l in range(nl)])
         ctx.nl, ctx.relu_last, ctx.training = nl, int(relu_last), int(training)
         ctx.wshapes = [params[4 * l].shape for l in range(nl)]
+        ctx.sinks = [_sink_view(t) for t in params]
         return y
 
     @staticmethod
@@ -431,12 +569,10 @@ class MlpStackFn(torch.autograd.Function):
             w = ws_[l]
             layers[l] = L.BnLayer(_p(w), _p(gammas[l]), _p(gammas[l]), _p(gammas[l]), _p(gammas[l]),
                                   _p(gammas[l]), None, w.shape[1], w.shape[0])
-            dw = torch.empty_like(w)
-            db = torch.empty(w.shape[0], dtype=torch.float32, device=dev)
-            dg = torch.empty_like(db)
-            dbt = torch.empty_like(db)
-            grads[l] = L.BnLayerGrad(_p(dw), _p(db), _p(dg), _p(dbt))
-            outs += [dw.reshape(ctx.wshapes[l]), db, dg, dbt]
+            co = w.shape[0]
+            bufs = [_grad_buf(ctx.sinks[4 * l + i], w.shape if i == 0 else (co,), dev) for i in range(4)]
+            grads[l] = L.BnLayerGrad(*[_p(b[0]) for b in bufs])
+            outs += bufs
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         nb = L.lib().prh_mlp_stack_workspace_bytes(P, nl, layers)
         ws = _ws(dev, nb)
@@ -445,7 +581,11 @@ class MlpStackFn(torch.autograd.Function):
                                                _p(coef[2]), _p(coef[3]), grads, _p(dx), _p(ws),
                                                ws.numel(), dev.index, _stream(dev)),
                 "prh_mlp_stack_backward")
-        return (dx, None, None, None, None, None, *outs)
+        rets = []
+        for i, (buf, tok) in enumerate(outs):
+            g = _grad_ret(buf, tok)
+            rets.append(g.reshape(ctx.wshapes[i // 4]) if (g is not None and i % 4 == 0) else g)
+        return (dx, None, None, None, None, None, *rets)
 
 
 def mlp_stack(x, layers: Sequence[Sequence[torch.Tensor]], buffers: Sequence[torch.Tensor],
@@ -542,6 +682,7 @@ class EncoderFn(torch.autograd.Function):
             ctx.training = int(training)
             ctx.gemm_mode = gemm_mode
             ctx.pshapes = [t.shape for t in params]
+            ctx.sinks = [_sink_view(t) for t in params]
             ctx.consumed = False
         # bound of max(fused) from the fusion statistics (training, split-fp16 cores), else None
         ctx_amax = coef[4, 6:7] if (training and need_bwd and gemm_mode == 3) else None
@@ -579,6 +720,7 @@ class EncoderFn(torch.autograd.Function):
             ctx.has_argmax = argmax is not None
             ctx.training = int(training)
             ctx.pshapes = [t.shape for t in params]
+            ctx.sinks = [_sink_view(t) for t in params]
             ctx.consumed = False
         EncoderFn.last_fused_amax = None
         return (gfeat if want_global else None), fused
@@ -600,7 +742,8 @@ class EncoderFn(torch.autograd.Function):
         prm = _enc_params_struct(p2, None, Cin)
         sv = L.EncoderSavedBf16(_p(z_cat), _p(z_fus), _p(gate), _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]),
                                 _p(argmax) if ctx.has_argmax else None)
-        g = [torch.empty_like(t) for t in p2]
+        gb = [_grad_buf(ctx.sinks[i], t.shape, dev) for i, t in enumerate(p2)]
+        g = [b_[0] for b_ in gb]
         gr = L.EncoderGrads()
         for k in range(5):
             gr.conv[k] = L.BnLayerGrad(_p(g[2 * k]), _p(g[2 * k + 1]), _p(g[10 + 2 * k]), _p(g[11 + 2 * k]))
@@ -612,7 +755,8 @@ class EncoderFn(torch.autograd.Function):
         L.check(L.lib().prh_encoder_backward_bf16(C.byref(prm), _p(x), B, N, ctx.training, _p(d_fused), _p(d_gfeat),
                                                   C.byref(sv), C.byref(gr), _p(dx), _p(ws), ws.numel(), dev.index,
                                                   _stream(dev)), "prh_encoder_backward_bf16")
-        grads = [gi.reshape(s) for gi, s in zip(g, ctx.pshapes)]
+        grads = [_grad_ret(*b_) for b_ in gb]
+        grads = [gi.reshape(s) if gi is not None else None for gi, s in zip(grads, ctx.pshapes)]
         return (dx, None, None, None, None, None, *grads)
 
     @staticmethod
@@ -640,7 +784,8 @@ class EncoderFn(torch.autograd.Function):
         sv = L.EncoderSaved(_p(z_cat), _p(z_fus), _p(gate), _p(coef[0]), _p(coef[1]), _p(coef[2]),
                             _p(coef[3]), _p(argmax) if ctx.has_argmax else None,
                             _p(coef[4]) if same_mode else None)
-        g = [torch.empty_like(t) for t in p2]
+        gb = [_grad_buf(ctx.sinks[i], t.shape, dev) for i, t in enumerate(p2)]
+        g = [b_[0] for b_ in gb]
         gr = L.EncoderGrads()
         for k in range(5):
             gr.conv[k] = L.BnLayerGrad(_p(g[2 * k]), _p(g[2 * k + 1]), _p(g[10 + 2 * k]), _p(g[11 + 2 * k]))
@@ -653,7 +798,8 @@ class EncoderFn(torch.autograd.Function):
                                              _p(d_gfeat), C.byref(sv), C.byref(gr), _p(dx), _p(ws),
                                              ws.numel(), dev.index, _stream(dev)),
                 "prh_encoder_backward")
-        grads = [gi.reshape(s) for gi, s in zip(g, ctx.pshapes)]
+        grads = [_grad_ret(*b_) for b_ in gb]
+        grads = [gi.reshape(s) if gi is not None else None for gi, s in zip(grads, ctx.pshapes)]
         return (dx, None, None, None, None, None, *grads)
 
 
@@ -1011,6 +1157,7 @@ class AddDropoutLayerNormFn(torch.autograd.Function):
         if need:
             ctx.save_for_backward(x2, r2, gamma, mean, rstd)
             ctx.p, ctx.seed, ctx.shape = float(p), int(seed), x.shape
+            ctx.g_sink, ctx.b_sink = _sink_view(gamma), _sink_view(beta)
         return y.view(x.shape)
 
     @staticmethod
@@ -1019,14 +1166,14 @@ class AddDropoutLayerNormFn(torch.autograd.Function):
         dev, rows = x2.device, x2.shape[0]
         dy2 = dy.contiguous().view(-1, 256)
         dx, dr = torch.empty_like(x2), torch.empty_like(x2)
-        dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
+        (dg, tg), (db, tb) = _grad_buf(ctx.g_sink, gamma.shape, dev), _grad_buf(ctx.b_sink, gamma.shape, dev)
         nb = L.lib().prh_add_dropout_layernorm_workspace_bytes()
         ws = _ws(dev, nb)
         L.check(L.lib().prh_add_dropout_layernorm_backward(_p(dy2), _p(x2), _p(r2), _p(gamma), _p(mean), _p(rstd), rows,
                                                            256, ctx.p, ctx.seed, _p(dx), _p(dr), _p(dg), _p(db), _p(ws),
                                                            ws.numel(), dev.index, _stream(dev)),
                 "prh_add_dropout_layernorm_backward")
-        return dx.view(ctx.shape), dr.view(ctx.shape), dg, db, None, None, None
+        return dx.view(ctx.shape), dr.view(ctx.shape), _grad_ret(dg, tg), _grad_ret(db, tb), None, None, None
 
 
 def add_dropout_layernorm(x, r, norm: torch.nn.LayerNorm, p: float):

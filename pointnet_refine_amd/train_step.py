@@ -156,6 +156,8 @@ class TrainStep:
         self.chunk = decoder_chunk
         self.world, self.group = world_size, group
         self.grads = FlatGrads(model.parameters())
+        from . import ops
+        ops.register_grad_sinks(zip(self.grads.params, self.grads.views))
         self.opt = optimizer if optimizer is not None else FlatAdam(self.grads, lr=lr)
         distributed = dist.is_available() and dist.is_initialized()
         self.bufs = FlatBuffers(model) if (distributed and broadcast_buffers) else None
@@ -166,6 +168,14 @@ class TrainStep:
         return self.loss_fn(out, target, denom)
 
     def forward_backward(self, context, noisy_line, target):
+        """One (micro-batched) forward + loss + backward.  The gradient buffer must be zero on
+        entry (grads.zero()): inside, the library's backward kernels write parameter gradients
+        straight into it (ops gradient sinks) instead of going through autograd's accumulation."""
+        from . import ops
+        with ops.sinks_active(new_step=True):
+            return self._forward_backward(context, noisy_line, target)
+
+    def _forward_backward(self, context, noisy_line, target):
         m = self.model
         if self.loss_fn is deep_supervision_l1:
             if self.geometry is None:
@@ -219,6 +229,12 @@ class TrainStep:
                 pass
             self._seed = None
         self._graph, self._static, self._static_loss = None, None, None
+        if getattr(self, "grads", None) is not None:
+            try:
+                from . import ops
+                ops.clear_grad_sinks(self.grads.params)
+            except Exception:
+                pass
 
     def __del__(self):
         self.close()

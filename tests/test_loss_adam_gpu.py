@@ -189,3 +189,47 @@ def test_graph_captured_step_matches_eager_step():
         assert all(torch.isfinite(torch.tensor(l3))) and len({round(v, 7) for v in l3}) == 3, l3
     finally:
         _lib.lib().prh_set_dropout_seed_source(None)
+
+
+@pytest.mark.parametrize("chunk", [None, 8])
+def test_gradient_sinks_match_autograd_accumulation(chunk):
+    """TrainStep hands the flat gradient buffer to the library's backward kernels (ops gradient
+    sinks: the first contribution of a step overwrites a parameter's region, later ones are
+    added, the Functions return None).  Same gradients as plain autograd accumulation into
+    zeroed .grad tensors, with dropout on and the decoder micro-batched or not."""
+    from pointnet_refine_amd import ops
+    from pointnet_refine_amd.model import LineRefineNet
+    from pointnet_refine_amd.synth import synthetic_batch
+    from pointnet_refine_amd.train_step import TrainStep
+    torch.manual_seed(11)
+    a = LineRefineNet().cuda().train()
+    b = LineRefineNet().cuda().train()
+    b.load_state_dict(a.state_dict())
+    ctx, noisy, target = synthetic_batch(16, 256, torch.device("cuda", 0))
+    sa = TrainStep(a, decoder_chunk=chunk)
+    torch.manual_seed(5)                     # dropout seeds are drawn from torch's CPU generator
+    sa.grads.zero()
+    la = sa.forward_backward(ctx, noisy, target)
+    assert len(ops._SINK_WRITTEN) >= len(sa.grads.params) - 8, len(ops._SINK_WRITTEN)   # nearly every parameter went direct
+    assert not ops._SINKS_ACTIVE
+    # plain autograd on the twin: no TrainStep, no sinks; poisoned .grad would show an overwrite
+    torch.manual_seed(5)
+    sb = TrainStep(b, decoder_chunk=chunk)
+    ops.clear_grad_sinks(sb.grads.params)    # registered by the constructor: take them away again
+    sb.grads.zero()
+    lb = sb.forward_backward(ctx, noisy, target)
+    assert len(ops._SINK_WRITTEN) == 0
+    assert abs(float(la) - float(lb)) < 1e-6
+    for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert p.grad is not None and q.grad is not None, k
+        scale = float(q.grad.abs().max()) + 1e-12
+        assert maxdiff(p.grad, q.grad) <= 2e-6 * scale + 1e-9, (k, maxdiff(p.grad, q.grad), scale)
+    # a second step through the sinks starts from a zeroed buffer again: no carry-over
+    torch.manual_seed(5)
+    sa.grads.zero()
+    sa.forward_backward(ctx, noisy, target)
+    for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        scale = float(q.grad.abs().max()) + 1e-12
+        assert maxdiff(p.grad, q.grad) <= 2e-6 * scale + 1e-9, k
+    sa.close()
+    assert not any(id(p) in ops._GRAD_SINKS for p in sa.grads.params)
