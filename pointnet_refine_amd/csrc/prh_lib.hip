@@ -345,27 +345,27 @@ inline bool small_nt_ok(const NTParams& p, bool nn) {
   if (nn && (p.N & 31)) return false;
   return true;
 }
-template <int TM, int TN, int KS, bool NN>
+template <int TM, int TN, int KS, bool NN, int EPI = EPI_BIAS>
 int launch_small_cfg(NTParams& p, hipStream_t st) {
-  static const int attr = allow_big_lds(gemm_small_kernel<TM, TN, KS, NN>);
+  static const int attr = allow_big_lds(gemm_small_kernel<TM, TN, KS, NN, EPI>);
   if (attr != PRH_OK) return attr;
   p.tiles_n = cdiv(p.N, TN * 32);
   const long tiles = (long)p.tiles_n * cdiv(p.M, TM * 32);
   char nm[64];
-  snprintf(nm, sizeof(nm), "gemm_small<%d%d%d,%s> K=%d N=%d", TM, TN, KS, NN ? "nn" : "nt", p.K, p.N);
-  const double by = 4.0 * ((double)p.M * p.K + (double)p.M * p.N * ((p.flags & F_RESID) ? 2 : 1) + (double)p.N * p.K);
+  snprintf(nm, sizeof(nm), "gemm_small<%d%d%d,%s,%d> K=%d N=%d", TM, TN, KS, NN ? "nn" : "nt", EPI, p.K, p.N);
+  const double by = 4.0 * ((double)p.M * p.K + (double)p.M * p.N * ((p.flags & F_RESID) || EPI == EPI_DGRAD ? 2 : 1) + (double)p.N * p.K);
   ProfScope ps(nm, 2.0 * p.M * (double)p.N * p.K, by, st);
-  hipLaunchKernelGGL((gemm_small_kernel<TM, TN, KS, NN>), dim3((unsigned)tiles), dim3(256), (small_lds<TM, TN, KS>()), st, p);
+  hipLaunchKernelGGL((gemm_small_kernel<TM, TN, KS, NN, EPI>), dim3((unsigned)tiles), dim3(256), (small_lds<TM, TN, KS>()), st, p);
   LAUNCH_CHECK();
   return PRH_OK;
 }
-template <bool NN>
+template <bool NN, int EPI = EPI_BIAS>
 int launch_small(NTParams& p, hipStream_t st) {
   p.flags &= ~F_POOL;
   const bool n64 = !NN || (p.N & 63) == 0;
-  if (n64 && (long)cdiv(p.M, 64) * cdiv(p.N, 64) >= 192) return launch_small_cfg<2, 2, 1, NN>(p, st);
-  if (n64 && (long)cdiv(p.M, 32) * cdiv(p.N, 64) >= 192) return launch_small_cfg<1, 2, 2, NN>(p, st);
-  return launch_small_cfg<1, 1, 4, NN>(p, st);
+  if (n64 && (long)cdiv(p.M, 64) * cdiv(p.N, 64) >= 192) return launch_small_cfg<2, 2, 1, NN, EPI>(p, st);
+  if (n64 && (long)cdiv(p.M, 32) * cdiv(p.N, 64) >= 192) return launch_small_cfg<1, 2, 2, NN, EPI>(p, st);
+  return launch_small_cfg<1, 1, 4, NN, EPI>(p, st);
 }
 // wgrad: 64 x 64 tiles, rows split in multiples of 64 until ~2 rounds of workgroups exist
 constexpr int TN_SMALL_MAX_P = 16384;
@@ -617,6 +617,17 @@ int launch_tn(TNParams& p, float* slab, float* colsum_slab, float* C, long ldc, 
       }
     }
     if constexpr (PROA == PRO_NONE && PROB == PRO_NONE) {
+      // short row ranges: one launch, no slab (prh_small.hpp, gemm_tn_direct_kernel)
+      if (!done && g_small && C != nullptr && p.P >= 64 && p.P <= 4096 && (p.P & 63) == 0 && (p.Mo & 31) == 0 &&
+          (p.Ni & 31) == 0 && (p.lda & 3) == 0 && (p.ldb & 3) == 0 && al16(p.A) && al16(p.B)) {
+        p.tiles_m = p.Mo / 32; p.tiles_n = p.Ni / 32; p.splits = 1; p.rows_per_split = p.P;
+        snprintf(nm, sizeof(nm), "gemm_tn_direct Mo=%d Ni=%d", p.Mo, p.Ni);
+        ProfScope ps(nm, 2.0 * p.P * (double)p.Mo * p.Ni, by, st);
+        hipLaunchKernelGGL(gemm_tn_direct_kernel, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(256), 0, st, p, C, ldc,
+                           colsum_out);
+        LAUNCH_CHECK();
+        return PRH_OK;
+      }
       if (!done && small_tn_dims_ok(p.P, p.Mo, p.Ni) && (p.lda & 3) == 0 && (p.ldb & 3) == 0 && al16(p.A) && al16(p.B)) {
         static const int attr_sm = allow_big_lds(gemm_tn_small_kernel);
         if (attr_sm != PRH_OK) return attr_sm;

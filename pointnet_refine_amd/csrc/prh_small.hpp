@@ -49,7 +49,7 @@ __device__ __forceinline__ void sm_dma_rows128(const float* base, long ld, int r
 //   NN = false: W is [N][K] (ld ldw)           - the forward of a Linear
 //   NN = true : W is [K][N] (ld ldw)           - its dgrad with the weight as stored
 // Requires K % 64 == 0, lda % 4 == 0, ldw % 4 == 0; NN also N % (32 TN) == 0.
-template <int TM, int TN, int KS, bool NN>
+template <int TM, int TN, int KS, bool NN, int EPI = EPI_BIAS>
 __global__ __launch_bounds__(256) void gemm_small_kernel(const NTParams p) {
   static_assert(TM * TN * KS == 4, "four waves");
   constexpr int BMs = TM * 32, BNs = TN * 32;
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const NTParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[0][0][r] += red[(s * TM * TN + wt) * 1024 + r * 64 + lane];
   }
-  nt_epilogue<EPI_BIAS, 1, 1>(acc, p, m0 + wm, n0 + wn, 0, lane);
+  nt_epilogue<EPI, 1, 1>(acc, p, m0 + wm, n0 + wn, (m0 + wm) >> 5, lane);
 }
 template <int TM, int TN, int KS>
 constexpr int small_lds() {
@@ -143,8 +143,8 @@ constexpr int small_lds() {
 }
 
 // wgrad: slab[split][Mo][Ni] = sum over this split's rows of A[p][Mo]^T B[p][Ni], 64 x 64 tiles,
-// rows_per_split a multiple of 64 (rows beyond P are clamped to P - 1 and masked out by ... no:
-// the launcher requires P % 64 == 0).  colsum[split][Mo] = column sums of A (tile_n == 0).
+// rows_per_split a multiple of 64 (the launcher requires P, Mo and Ni to be multiples of 64).
+// colsum[split][Mo] = column sums of A (tile_n == 0).
 __global__ __launch_bounds__(256) void gemm_tn_small_kernel(const TNParams p) {
   constexpr int T_BYTES = 64 * 256, STAGE = 2 * T_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -211,6 +211,82 @@ __global__ __launch_bounds__(256) void gemm_tn_small_kernel(const TNParams p) {
     red[wave * 64 + lane] = csum;
     __syncthreads();
     if (tid < 64) p.colsum[(size_t)split * p.Mo + m0 + tid] = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
+  }
+}
+
+
+// wgrad without a slab: C[Mo,Ni] (ld ldc) = A[P,Mo]^T B[P,Ni], colsum_out[Mo] = column sums of A
+// (optional), for short row ranges (P <= 4096).  One 32 x 32 output tile per workgroup; the four
+// waves split every 64-row k-tile (16 rows each) and add their blocks through LDS, so the result
+// is written once, in a fixed order, and no reduction launch follows.  P % 64 == 0, Mo % 32 == 0,
+// Ni % 32 == 0.
+__global__ __launch_bounds__(256) void gemm_tn_direct_kernel(const TNParams p, float* __restrict__ C, long ldc,
+                                                             float* __restrict__ colsum_out) {
+  constexpr int T_BYTES = 64 * 128, STAGE = 2 * T_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int tile_n = blockIdx.x % p.tiles_n, tile_m = blockIdx.x / p.tiles_n;
+  const int m0 = tile_m * 32, n0 = tile_n * 32;
+  const int nk = p.P / SM_BK;
+  const unsigned lds0 = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)smem);
+  auto dma = [&](int kt, int stage) {
+    const unsigned sb = lds0 + stage * STAGE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = __builtin_amdgcn_readfirstlane(wave + 4 * i);
+      if (q < 8) sm_dma_rows128(p.A, p.lda, kt * SM_BK, p.P - 1, m0, q, sb, lane);
+      else sm_dma_rows128(p.B, p.ldb, kt * SM_BK, p.P - 1, n0, q - 8, sb + T_BYTES, lane);
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const bool do_colsum = colsum_out != nullptr && tile_n == 0;
+  float csum = 0.f;
+  if (nk > 0) dma(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) {
+      dma(kt + 1, (kt + 1) & 1);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    const float* As = reinterpret_cast<const float*>(smem + (kt & 1) * STAGE) + wave * 16 * 32;
+    const float* Bs = As + 64 * 32;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const float a = As[(kk * 2 + half) * 32 + l31];
+      const float bb = Bs[(kk * 2 + half) * 32 + l31];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc, 0, 0, 0);
+    }
+    if (do_colsum) {     // lane = (column l31, rows 8 half .. of this wave's 16)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) csum += As[(half * 8 + r) * 32 + l31];
+    }
+    __syncthreads();
+  }
+  float* red = reinterpret_cast<float*>(smem);          // [3][16][64] blocks + [4][64] column sums
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
+  }
+  if (do_colsum) red[3 * 1024 + wave * 64 + lane] = csum;
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += red[(s * 16 + r) * 64 + lane];
+    const int col = n0 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) C[(size_t)(m0 + crow(r, half)) * ldc + col] = acc[r];
+  } else if (wave == 1 && do_colsum && lane < 32) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s += red[3 * 1024 + w * 64 + lane] + red[3 * 1024 + w * 64 + 32 + lane];
+    colsum_out[m0 + lane] = s;
   }
 }
 

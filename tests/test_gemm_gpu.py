@@ -53,7 +53,7 @@ def test_gemm_nt(lib, m, n, k):
                                      (20000, 1024, 1984),
                                      # small wgrad core: rows and both widths multiples of 64
                                      (1024, 256, 256), (1024, 1024, 256), (64, 64, 64), (4096, 128, 1024),
-                                     (1088, 256, 192)])
+                                     (1088, 256, 192), (6144, 128, 64), (2048, 96, 32)])
 def test_gemm_tn(lib, p, mo, ni):
     g = torch.Generator(device="cuda").manual_seed(p + mo + ni)
     a = torch.randn(p, mo, device="cuda", generator=g)
