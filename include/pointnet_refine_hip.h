@@ -225,6 +225,12 @@ int prh_linear_forward_full(const float* x, long ldx, const float* w, const floa
 size_t prh_operand_absmax_workspace_bytes(void);
 int prh_operand_absmax(const float* x, long ld, long rows, int cols, float* out, void* workspace,
                        size_t workspace_bytes, int device, void* stream);
+/* ReLU backward of a Linear with the ReLU fused into its epilogue (src/model.py:131 linear1 +
+ * activation; :162-166 reg_branches): out = y > 0 ? dy : 0 and amax_out[0] = max|out| (the operand
+ * maximum of the split-fp16 backward GEMMs) in one pass.  n elements, n % 4 == 0, contiguous.
+ * Workspace: prh_operand_absmax_workspace_bytes(). */
+int prh_relu_mask_absmax(const float* dy, const float* y, float* out, long n, float* amax_out, void* workspace,
+                         size_t workspace_bytes, int device, void* stream);
 int prh_linear_uses_operand_maxima(int rows, int k, int n);
 
 /* First layer of the positional-encoding MLP (src/model.py:64-75, nn.Linear(3, hidden) + ReLU)

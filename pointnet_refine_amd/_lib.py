@@ -78,7 +78,7 @@ EXPORTS = [
     "prh_l1_loss_workspace_bytes", "prh_l1_loss", "prh_adam_step",
     "prh_add_dropout_layernorm_forward", "prh_add_dropout_layernorm_workspace_bytes",
     "prh_add_dropout_layernorm_backward",
-    "prh_set_gemm_mode", "prh_get_gemm_mode", "prh_set_dropout_seed_source",
+    "prh_relu_mask_absmax", "prh_set_gemm_mode", "prh_get_gemm_mode", "prh_set_dropout_seed_source",
     "prh_last_error", "prh_version",
 ]
 
@@ -216,6 +216,8 @@ def _bind(lib):
     lib.prh_l1_loss.argtypes = [vp, vp, i, lg, C.c_double, i, vp, vp, vp, C.c_double, vp, C.c_size_t, i, vp]
     lib.prh_adam_step.restype = i
     lib.prh_adam_step.argtypes = [vp, vp, vp, vp, lg, f, f, f, f, f, i, i, vp]
+    lib.prh_relu_mask_absmax.restype = i
+    lib.prh_relu_mask_absmax.argtypes = [vp, vp, vp, lg, vp, vp, sz, i, vp]
     lib.prh_set_gemm_mode.restype = i
     lib.prh_set_gemm_mode.argtypes = [i]
     lib.prh_attn_backward_ex.restype = i

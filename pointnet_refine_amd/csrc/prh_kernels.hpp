@@ -429,6 +429,29 @@ __global__ void slab_reduce2_kernel(const float* __restrict__ slab, int S, int r
   }
 }
 
+// out = y > 0 ? dy : 0 over n floats (n % 4 == 0), per-block max|out| into part[blockIdx.x]:
+// the ReLU backward of a Linear with a fused ReLU, and the operand maximum the backward GEMMs
+// need, in one pass (it was a compare, a select and a maximum pass)
+__global__ __launch_bounds__(256) void relu_mask_amax_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                             float* __restrict__ out, size_t n4,
+                                                             float* __restrict__ part) {
+  __shared__ float red[4];
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 g = reinterpret_cast<const float4*>(dy)[i];
+    const float4 v = reinterpret_cast<const float4*>(y)[i];
+    float4 o;
+    o.x = v.x > 0.f ? g.x : 0.f; o.y = v.y > 0.f ? g.y : 0.f; o.z = v.z > 0.f ? g.z : 0.f; o.w = v.w > 0.f ? g.w : 0.f;
+    reinterpret_cast<float4*>(out)[i] = o;
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
 // dst[r][0..cd) = src[r][0..cs) zero-padded (cd >= cs); or truncation when cd < cs
 __global__ void copy_cols_kernel(const float* __restrict__ src, long lds_, int cs, float* dst,
                                  long ldd, int cd, size_t rows) {

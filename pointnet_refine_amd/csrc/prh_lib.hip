@@ -1130,6 +1130,25 @@ int prh_operand_absmax(const float* x, long ld, long rows, int cols, float* out,
                                    (hipStream_t)stream)));
   return PRH_OK;
 }
+// out = (y > 0 ? dy : 0), amax_out[0] = max|out|: ReLU backward of a Linear with a fused ReLU
+// (src/model.py:131,164 - linear1 + activation, reg_branches[i][0:2]); n = element count, % 4 == 0,
+// all three buffers contiguous and 16-B aligned.  Workspace: prh_operand_absmax_workspace_bytes().
+int prh_relu_mask_absmax(const float* dy, const float* y, float* out, long n, float* amax_out, void* workspace,
+                         size_t workspace_bytes, int device, void* stream) {
+  if (!dy || !y || !out || !amax_out || n < 0 || (n & 3)) return fail(PRH_ERR_ARG, "relu_mask_absmax: bad argument");
+  HIP_TRY(hipSetDevice(device));
+  Arena a(workspace, workspace_bytes);
+  float* part = a.f(ABSMAX_MAX_BLOCKS);
+  if (!a.ok) return fail(PRH_ERR_WORKSPACE, "relu_mask_absmax: workspace too small (%zu bytes)", workspace_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  long blocks = cdiv(n / 4, 256L * 4);
+  blocks = blocks < 1 ? 1 : (blocks > ABSMAX_MAX_BLOCKS ? ABSMAX_MAX_BLOCKS : blocks);
+  hipLaunchKernelGGL(relu_mask_amax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dy, y, out, (size_t)(n / 4), part);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(absmax_final_kernel, dim3(1), dim3(256), 0, st, (const float*)part, (int)blocks, amax_out);
+  LAUNCH_CHECK();
+  return PRH_OK;
+}
 // 1 when a [rows,k] x [n,k]^T Linear GEMM (and its backward GEMMs) run on the split-fp16 cores,
 // i.e. when operand maxima are consumed at all
 int prh_linear_uses_operand_maxima(int rows, int k, int n) {

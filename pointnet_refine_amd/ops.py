@@ -326,12 +326,18 @@ class LinearFn(torch.autograd.Function):
         dy2 = dy.reshape(rows, n)
         hint = _DY_AMAX.pop(dy.data_ptr(), None) if _DY_AMAX else None
         dy_amax = hint[0] if (hint is not None and hint[1] == tuple(dy.shape) and dy2.data_ptr() == dy.data_ptr()) else None
-        if ctx.relu:
-            dy2 = torch.where(y > 0, dy2, torch.zeros((), dtype=dy2.dtype, device=dy2.device))
-            dy_amax = None
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         dev = x2.device
+        if ctx.relu:          # mask by the saved output and take max|masked dy| in the same pass
+            if dy2.dtype != torch.float32:
+                dy2 = dy2.float()
+            masked = torch.empty_like(dy2)
+            dy_amax = torch.empty(1, dtype=torch.float32, device=dev)
+            wsm = _ws(dev, L.lib().prh_operand_absmax_workspace_bytes())
+            L.check(L.lib().prh_relu_mask_absmax(_p(dy2), _p(y), _p(masked), dy2.numel(), _p(dy_amax), _p(wsm),
+                                                 wsm.numel(), dev.index, _stream(dev)), "prh_relu_mask_absmax")
+            dy2 = masked
         need_dx, need_dw, need_db = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         dx = torch.empty_like(x2) if need_dx else None
         dw, tw = _grad_buf(ctx.w_sink, w.shape, dev, need_dw)
