@@ -86,6 +86,9 @@ def parse():
                     help="second workload (not the headline metric): MultiScalePointNetEncoder.forward returning "
                          "(global_feat, fused) - the north_star's fused shared-MLP + max-pool - alone: train-mode "
                          "forward+backward, or with --eval the inference forward through the single fused kernel")
+    ap.add_argument("--pool", action="store_true",
+                    help="with --encoder-only: accepted for the command line the round-1 review names "
+                         "(`--encoder-only --pool`); the dual max + mean pooling is always part of that workload")
     ap.add_argument("--eval", action="store_true", help="with --encoder-only: eval-mode forward only (fused kernel)")
     ap.add_argument("--stub", action="store_true",
                     help="launcher self-test: a small CPU stand-in model over the gloo backend instead of "
@@ -182,6 +185,15 @@ def cpu_baseline(points, batch):
                       f"encoder_fwd_bwd = MultiScalePointNetEncoder alone; eval_forward = no_grad forward"}
 
 
+def kernel_sources_sha():
+    """Same fingerprint as scripts/pmc_traffic.py records next to the counters."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("prh_gemm.hpp", "prh_gemm_s3.hpp", "prh_gemm_h2.hpp", "prh_b16.hpp", "prh_attn16.hpp", "prh_fused.hpp"):
+        h.update(open(os.path.join(ROOT, "pointnet_refine_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(dname, batch, points, mode):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE x2
     + WRITE_SIZE, separate rocprofv3 --pmc runs of this same command, scripts/pmc_traffic.sh).
@@ -195,6 +207,11 @@ def pmc_traffic(dname, batch, points, mode):
     if not os.path.exists(path):
         return None, None
     recs = json.load(open(path))
+    # the counters describe the kernels as they were when the passes ran: a file taken before the
+    # last edit of the kernel sources is not used (traffic null, the file name says "stale")
+    sha = recs[0].get("kernel_sources_sha") if recs else None
+    if sha is not None and sha != kernel_sources_sha():
+        return None, fn + " (stale: kernel sources changed since the PMC passes)"
     ma = re.match(r"attn16_(fwd|bwd)<(split|bf16)>", dname)
     m = re.match(r"gemm_(nt|tn)_(h2|b16)(tr)?<(\d),(\d)>", dname)
     if ma:

@@ -10,6 +10,21 @@ import json
 import os
 import sys
 
+import hashlib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNEL_SOURCES = ("prh_gemm.hpp", "prh_gemm_s3.hpp", "prh_gemm_h2.hpp", "prh_b16.hpp", "prh_attn16.hpp", "prh_fused.hpp")
+
+
+def kernel_sources_sha():
+    """Fingerprint of the kernel sources the counters belong to: bench.py drops the lookup
+    (traffic null) when the tree's fingerprint differs from the one recorded here."""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "pointnet_refine_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 d, out = sys.argv[1], sys.argv[2]
 MIN_BYTES = float(sys.argv[3]) if len(sys.argv) > 3 else 1e9      # skip launches that fetch less than this
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -41,6 +56,7 @@ for (name, wgs), m in acc.items():
                 "write_bytes_per_launch": (sum(wr) / len(wr) * 1024) if wr else None,
                 "fetch_bytes_largest_launch": fe[imax] * 1024 * 2,
                 "write_bytes_largest_launch": (wr[imax] * 1024) if (wr and len(wr) == len(fe)) else None,
+                "kernel_sources_sha": kernel_sources_sha(),
                 "note": "FETCH_SIZE x2 (gfx950 half-count correction), WRITE_SIZE as read; separate --pmc passes"})
 res.sort(key=lambda r: -r["fetch_bytes_largest_launch"])
 json.dump(res, open(out, "w"), indent=1)
