@@ -73,7 +73,7 @@ def load_scene_items(json_path):
 
 @torch.no_grad()
 def refine_scene(model, pcd_points, raw_lines, num_line_points=32, num_context_points=1024,
-                 crop_radius=0.3, decay_scale=2.0, batch_lines=512, seed=0, precision=None):
+                 crop_radius=0.3, decay_scale=2.0, batch_lines=2048, seed=0, precision=None):
     """Refine every polyline of a scene (inference_whole_scene.py:94-146, NUM_CONTEXT_POINTS 1024,
     CROP_RADIUS 0.3).  pcd_points (P,4) numpy or CUDA tensor; raw_lines list of (n_i,3).
     Returns (refined (L,M,3), noisy_resampled (L,M,3)) numpy arrays in scene coordinates.

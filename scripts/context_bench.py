@@ -54,18 +54,19 @@ ref = None
 for prec, what in (("layers", "per-layer eval kernels (round-1 path), fp32-accurate"),
                    ("fp32", "fused encoder kernel, fp32-accurate (2 fp16 planes)"),
                    ("fp16", "fused encoder kernel fp16 + decoder GEMMs bf16 (config 5)")):
-    refine_scene(model, ct, lines[:512], batch_lines=512, precision=prec)
+    BL = int(os.environ.get("BATCH_LINES", "2048"))
+    refine_scene(model, ct, lines[:BL], batch_lines=BL, precision=prec)
     torch.cuda.synchronize()
     best = 1e9
     for rep in range(3):
         t0 = time.perf_counter()
-        refined, _ = refine_scene(model, ct, lines, batch_lines=512, seed=1, precision=prec)
+        refined, _ = refine_scene(model, ct, lines, batch_lines=BL, seed=1, precision=prec)
         torch.cuda.synchronize()
         best = min(best, time.perf_counter() - t0)
     if ref is None:
         ref = refined
     print(f"refine_scene [{what}]: {L} lines end to end (device resampling + contexts + eval forward in batches "
-          f"of 512 + copy back) {best * 1e3:.0f} ms = {L / best:.0f} lines/s; max |refined - per-layer| "
+          f"of {BL} + copy back) {best * 1e3:.0f} ms = {L / best:.0f} lines/s; max |refined - per-layer| "
           f"{float(np.abs(refined - ref).max()):.2e}")
 nb = 16
 t0 = time.perf_counter()

@@ -17,7 +17,7 @@ from pointnet_refine_amd.synth import synthetic_batch
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
-bs = int(sys.argv[3]) if len(sys.argv) > 3 else 512
+bs = int(sys.argv[3]) if len(sys.argv) > 3 else 2048
 dev = torch.device("cuda", 0)
 lib = _lib.lib()
 torch.manual_seed(0)
