@@ -153,6 +153,19 @@ int prh_linear_backward_bf16(const uint16_t* x, long ldx, const float* w, const 
                              float* db, int rows, int k, int n, void* workspace, size_t workspace_bytes, int device,
                              void* stream);
 
+/* Inference-only cross-attention with the key / value projections folded in (src/model.py:119-128
+ * in eval mode): attention over the RAW rows X = memory + pos and Y = memory, which
+ * are the same for all six layers, instead of over per-layer projected buffers -
+ *   softmax(Q_h K_h^T) V_h = softmax((Q_h Wk_h) X^T) Y Wv_h^T + bv_h
+ * (the key bias is constant along the keys and drops out of the softmax).  prh_cast_perm_bf16 makes
+ * the bf16 row image the kernel reads from fp32 [rows, 256] (ld >= 256); prh_attn_fold_forward:
+ * q [B*M, 256] projected (unscaled) queries, wk / wv [256, 256] and bv [256] = rows d..2d and 2d..3d
+ * of the layer's packed in_proj parameters, o [B*M, 256] (before out_proj).  8 heads of 32 channels,
+ * M <= 32, bf16 products with fp32 accumulation (BASELINE config 5). */
+int prh_cast_perm_bf16(const float* src, long ld, uint16_t* dst, long rows, int device, void* stream);
+int prh_attn_fold_forward(const float* q, long ldq, const uint16_t* x16, const uint16_t* y16, const float* wk, long ldwk,
+                          const float* wv, long ldwv, const float* bv, float* o, long ldo, int B, int M, int N, int H,
+                          float scale, int device, void* stream);
 /* bf16 mode, decoder side: the cross-attention key / value projections of all six layers
  * (src/model.py:123-126) write their [rows, 6*256] outputs in bf16 and receive bf16 gradients.
  *   prh_linear_forward_out16: y bf16 [rows,n] = x W^T + b from an fp32 x;

@@ -78,7 +78,7 @@ EXPORTS = [
     "prh_l1_loss_workspace_bytes", "prh_l1_loss", "prh_adam_step",
     "prh_add_dropout_layernorm_forward", "prh_add_dropout_layernorm_workspace_bytes",
     "prh_add_dropout_layernorm_backward",
-    "prh_relu_mask_absmax", "prh_set_gemm_mode", "prh_get_gemm_mode", "prh_set_dropout_seed_source",
+    "prh_relu_mask_absmax", "prh_cast_perm_bf16", "prh_attn_fold_forward", "prh_set_gemm_mode", "prh_get_gemm_mode", "prh_set_dropout_seed_source",
     "prh_last_error", "prh_version",
 ]
 
@@ -216,6 +216,10 @@ def _bind(lib):
     lib.prh_l1_loss.argtypes = [vp, vp, i, lg, C.c_double, i, vp, vp, vp, C.c_double, vp, C.c_size_t, i, vp]
     lib.prh_adam_step.restype = i
     lib.prh_adam_step.argtypes = [vp, vp, vp, vp, lg, f, f, f, f, f, i, i, vp]
+    lib.prh_cast_perm_bf16.restype = i
+    lib.prh_cast_perm_bf16.argtypes = [vp, lg, vp, lg, i, vp]
+    lib.prh_attn_fold_forward.restype = i
+    lib.prh_attn_fold_forward.argtypes = [vp, lg, vp, vp, vp, lg, vp, lg, vp, vp, lg, i, i, i, i, C.c_float, i, vp]
     lib.prh_relu_mask_absmax.restype = i
     lib.prh_relu_mask_absmax.argtypes = [vp, vp, vp, lg, vp, vp, sz, i, vp]
     lib.prh_set_gemm_mode.restype = i

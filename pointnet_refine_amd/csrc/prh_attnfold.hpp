@@ -1,0 +1,235 @@
+// Inference-only cross-attention with the key / value PROJECTIONS FOLDED IN (VERDICT
+// r01 item 5; src/model.py:119-128 in eval mode).  The reference projects the memory to keys and
+// values per layer (two [B N, 256] x [256, 256] GEMMs) and attends over the results.  By
+// associativity the same numbers come out of attending over the RAW rows, which are the same for
+// all six layers and all eight heads:
+//   S_h = Q_h K_h^T = Q_h (X Wk_h^T + 1 bk_h^T)^T = (Q_h Wk_h) X^T + (Q_h bk_h) 1^T
+//         - the second term is constant along the keys and drops out of the softmax;
+//   O_h = P_h V_h = P_h (Y Wv_h^T + 1 bv_h^T) = (P_h Y) Wv_h^T + bv_h        (rows of P_h sum to 1)
+// with X = memory + pos and Y = memory.  So: no k_all / v_all buffers (12.9 GB per 2048 segments
+// in bf16), no projection GEMMs (14 of the 65 ms of a config-5 forward, bound by writing those
+// buffers), and the attention products become 256 deep instead of 32 - on a kernel that was bound
+// by vector-instruction issue, not by the matrix pipe.
+//
+// One workgroup = one segment, its 8 waves = the 8 heads.  A tile of 32 keys of X and of Y
+// (bf16, [32][256], LDS-DMA, double buffered) is shared by the 8 heads.  Per head:
+//   prologue  Q'^T[c][q] = sum_d Wk[h 32 + d][c] Q_h[q][d]       (8 blocks of 32 channels; kept as
+//             bf16 B-operand fragments: 64 registers)
+//   per tile  S^T[key][q] = sum_c X[key][c] Q'^T[c][q]            16 MFMAs 32x32x16
+//             online softmax (no dropout in eval mode)
+//             PY^T[c][q] += sum_key Y^T[c][key] P^T[key][q]        16 MFMAs, Y^T by transposed LDS reads
+//   epilogue  O^T[d][q] = (sum_c Wv[h 32 + d][c] PY^T[c][q]) / l[q] + bv
+// An accumulator tile is used as the B operand of the next product (prh_attn16.hpp): its registers
+// 8s..8s+7 hold rows 16s + 8(j>>2) + 4h2 + (j&3).  The X rows are therefore stored with bits 2 and
+// 3 of the channel index swapped inside every group of 16 (cast_perm_b16_kernel), so that the
+// eight channels a lane needs for k-step s are one 16-B chunk; with that storage the rows of PY^T
+// come out such that the Wv fragments are read in natural order.  bf16 operands, fp32 accumulation
+// (BASELINE config 5: 5e-2).
+#pragma once
+#include "prh_attn16.hpp"
+#include "prh_small.hpp"
+
+namespace prh {
+
+typedef unsigned short u16_t;
+constexpr int AF_ROW = 512;                 // bytes per key row: 256 bf16
+constexpr int AF_TILE = 32 * AF_ROW;        // 16 KB
+constexpr int AF_STAGE = 2 * AF_TILE;       // X tile | Y tile
+constexpr int AF_LDS = 3 * AF_STAGE;        // 96 KB: three stages, one barrier per tile
+
+// fp32 [rows][256] (ld) -> bf16 [rows][256], channel p of the output = channel swap23(p) of the input
+__global__ __launch_bounds__(256) void cast_perm_b16_kernel(const float* __restrict__ src, long ld,
+                                                            u16_t* __restrict__ dst, size_t rows) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per 16-channel group
+  if (i >= rows * 16) return;
+  const size_t r = i >> 4;
+  const int g = (int)(i & 15);
+  const float* s = src + r * ld + g * 16;
+  const float4 a = ldg4(s), b = ldg4(s + 4), c = ldg4(s + 8), d = ldg4(s + 12);
+  uint4 lo = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(c.x, c.y), pack_bf16x2(c.z, c.w));
+  uint4 hi = make_uint4(pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w), pack_bf16x2(d.x, d.y), pack_bf16x2(d.z, d.w));
+  uint4* o = reinterpret_cast<uint4*>(dst + r * 256 + g * 16);
+  o[0] = lo;      // positions 0..7  = channels 0..3, 8..11
+  o[1] = hi;      // positions 8..15 = channels 4..7, 12..15
+}
+
+struct AttnFoldParams {
+  const float* q; long ldq;          // [B*M, H*32] projected queries
+  const u16_t* x16; const u16_t* y16;   // [B*N, 256] bf16, channel-permuted: memory + pos, memory
+  const float* wk; long ldwk;        // [H*32, 256] key rows of the layer's in_proj_weight
+  const float* wv; long ldwv;        // [H*32, 256] value rows
+  const float* bv;                   // [H*32]
+  float* o; long ldo;                // [B*M, H*32]
+  int B, M, N, H;
+  float scale;
+};
+
+__device__ __forceinline__ bf16x8 af_pack(const float (&f)[8]) {
+  const uint4 u = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+  return __builtin_bit_cast(bf16x8, u);
+}
+
+__global__ __launch_bounds__(512, 2) void attn_fold_fwd_kernel(const AttnFoldParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, h = threadIdx.x >> 6;
+  const int h2 = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.x;
+  const unsigned lds0 = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)smem);
+
+  // key tiles: 32 pieces of 1 KB per stage (16 per tensor: 2 rows each), 4 per wave
+  auto dma = [&](int k0, int stage) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pc = __builtin_amdgcn_readfirstlane(h * 4 + i);
+      const int row = 2 * (pc & 15) + h2;
+      int key = k0 + row;
+      key = key < p.N ? key : p.N - 1;
+      // X: chunk ^ row (the 16 lanes of a row-read quarter hit 16 different chunks); Y: chunk ^ 2 row (the
+      // transposed reads take two adjacent chunks of four consecutive rows: eight different chunks)
+      const int sw = (pc >> 4) ? ((row << 1) & 31) : (row & 31);
+      const u16_t* src = ((pc >> 4) ? p.y16 : p.x16) + ((size_t)b * p.N + key) * 256 + ((l31 ^ sw) << 3);
+      glds16(src, lds0 + stage * AF_STAGE + (pc >> 4) * AF_TILE + (pc & 15) * 1024);
+    }
+  };
+  dma(0, 0);
+  dma(32, 1);       // (keys beyond N are clamped: a harmless copy when N <= 32)
+
+  // ---- prologue: Q'^T blocks as B fragments
+  bf16x8 qf[8][2];
+  {
+    float xq[16];
+    a16_load_rows(p.q, p.ldq, (long)b * p.M, p.M, h * 32, lane, xq);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) xq[t] *= p.scale;
+    float t0[8], t1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { t0[j] = xq[j]; t1[j] = xq[8 + j]; }
+    const bf16x8 qb0 = af_pack(t0), qb1 = af_pack(t1);
+    const float* wkh = p.wk + (size_t)(h * 32 + 8 * h2) * p.ldwk + l31;
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) {
+      float w0[8], w1[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        w0[j] = wkh[(size_t)j * p.ldwk + cb * 32];
+        w1[j] = wkh[(size_t)(16 + j) * p.ldwk + cb * 32];
+      }
+      f32x16 acc = a16_zero();
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af_pack(w0), qb0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af_pack(w1), qb1, acc, 0, 0, 0);
+      bf16x8 f0[1], f1[1];
+      a16_acc_frag<1>(acc, 0, f0);
+      a16_acc_frag<1>(acc, 1, f1);
+      qf[cb][0] = f0[0];
+      qf[cb][1] = f1[0];
+    }
+  }
+
+  f32x16 py[8];
+#pragma unroll
+  for (int cb = 0; cb < 8; ++cb) py[cb] = a16_zero();
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int g = lane >> 4, jj = lane & 15;
+  // three stages: tile kt is multiplied while tiles kt+1 and kt+2 are in flight; the barrier that
+  // publishes tile kt also says every wave is done with tile kt-1, whose stage takes tile kt+2
+  int stage = 0;
+  for (int k0 = 0; k0 < p.N; k0 += 32) {
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // this wave's pieces of tile kt (tile kt+1 may fly)
+    __syncthreads();
+    dma(k0 + 64, stage == 0 ? 2 : stage - 1);
+    const char* xt = smem + stage * AF_STAGE;
+    const char* yt = xt + AF_TILE;
+    // S^T[key][q]
+    f32x16 s = a16_zero();
+    {
+      const char* xr = xt + l31 * AF_ROW;
+#pragma unroll
+      for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          const int c = cb * 4 + 2 * st + h2;
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(xr + ((c ^ l31) << 4));
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[cb][st], s, 0, 0, 0);
+        }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[r] = (k0 + crow(r, h2) >= p.N) ? -INFINITY : s[r];
+      mx = fmaxf(mx, s[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = __expf(s[r] - m_new);
+      psum += e;
+      s[r] = e;
+    }
+    psum += __shfl_xor(psum, 32);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+    if (__any(alpha != 1.f)) {
+#pragma unroll
+      for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) py[cb][r] *= alpha;
+    }
+    // PY^T[c][q] += Y^T P^T
+    bf16x8 pf[2][1];
+    a16_acc_frag<1>(s, 0, pf[0]);
+    a16_acc_frag<1>(s, 1, pf[1]);
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const int row = 16 * st + 4 * (g >> 1) + (jj >> 2);
+      const char* yr0 = yt + row * AF_ROW;
+      const char* yr1 = yr0 + 8 * AF_ROW;
+#pragma unroll
+      for (int cb = 0; cb < 8; ++cb) {
+        const int col = cb * 32 + 16 * (g & 1) + 4 * (jj & 3);
+        const int ch = col >> 3, off = (col & 7) * 2;
+        const fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+            (__attribute__((address_space(3))) fp16x4*)(yr0 + ((ch ^ ((row << 1) & 31)) << 4) + off));
+        const fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+            (__attribute__((address_space(3))) fp16x4*)(yr1 + ((ch ^ (((row + 8) << 1) & 31)) << 4) + off));
+        struct Pair { fp16x4 a, b; } pr = {lo, hi};
+        const bf16x8 ya = __builtin_bit_cast(bf16x8, pr);
+        py[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ya, pf[st][0], py[cb], 0, 0, 0);
+      }
+    }
+    stage = stage == 2 ? 0 : stage + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no copy may land after the workgroup is gone
+
+  // ---- epilogue: O^T[d][q] = Wv_h PY^T / l + bv
+  const float inv = 1.f / l_run;
+  f32x16 oacc = a16_zero();
+  const float* wvh = p.wv + (size_t)(h * 32 + l31) * p.ldwv + 8 * h2;
+#pragma unroll
+  for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      float w[8];
+      const float4 wa = ldg4(wvh + cb * 32 + 16 * st), wb = ldg4(wvh + cb * 32 + 16 * st + 4);
+      w[0] = wa.x; w[1] = wa.y; w[2] = wa.z; w[3] = wa.w; w[4] = wb.x; w[5] = wb.y; w[6] = wb.z; w[7] = wb.w;
+      bf16x8 bfr[1];
+      a16_acc_frag<1>(py[cb], st, bfr);
+      oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af_pack(w), bfr[0], oacc, 0, 0, 0);
+    }
+  if (l31 < p.M) {
+    float* op = p.o + (size_t)((long)b * p.M + l31) * p.ldo + h * 32;
+    const float* bvh = p.bv + h * 32;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const float4 bb = ldg4(bvh + 8 * gq + 4 * h2);
+      *reinterpret_cast<float4*>(op + 8 * gq + 4 * h2) =
+          make_float4(fmaf(oacc[4 * gq], inv, bb.x), fmaf(oacc[4 * gq + 1], inv, bb.y), fmaf(oacc[4 * gq + 2], inv, bb.z),
+                      fmaf(oacc[4 * gq + 3], inv, bb.w));
+    }
+  }
+}
+
+}  // namespace prh

@@ -21,6 +21,7 @@
 #include "prh_gemm_h2.hpp"
 #include "prh_b16.hpp"
 #include "prh_small.hpp"
+#include "prh_attnfold.hpp"
 #include "prh_fused.hpp"
 #include "prh_context.hpp"
 #include "prh_kernels.hpp"
@@ -2343,6 +2344,39 @@ int prh_attn_backward_ex(const float* q, long ldq, const float* k, long ldk, con
   if (attr_rc) return fail(PRH_ERR_HIP, "attention_backward: cannot raise the dynamic LDS limit");
   ProfScope ps("attn_bwd", 14.0 * B * H * (double)M * N * 32, 4.0 * (4.0 * B * N * H * 32 + 4.0 * B * M * H * 32), st);
   hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(B * (H / wpb))), dim3(64 * wpb), lds, st, a);
+  LAUNCH_CHECK();
+  return PRH_OK;
+}
+/* Inference-only cross-attention over the RAW memory rows with the layer's key / value projections
+ * folded in (csrc/prh_attnfold.hpp).  prh_cast_perm_bf16: fp32 [rows, 256] (ld) -> the bf16 row image
+ * the kernel reads (channels permuted inside groups of 16).  prh_attn_fold_forward: q [B*M, 256]
+ * projected queries, x16 / y16 the images of memory + pos and of memory ([B*N, 256]), wk / wv / bv the
+ * key and value rows of the layer's packed in_proj parameters; o [B*M, 256].  8 heads of 32, M <= 32. */
+int prh_cast_perm_bf16(const float* src, long ld, uint16_t* dst, long rows, int device, void* stream) {
+  if (!src || !dst || rows < 0 || ld < 256 || (ld & 3)) return fail(PRH_ERR_ARG, "cast_perm_bf16: bad argument");
+  HIP_TRY(hipSetDevice(device));
+  if (rows == 0) return PRH_OK;
+  hipLaunchKernelGGL(cast_perm_b16_kernel, dim3((unsigned)cdiv(rows * 16, 256L)), dim3(256), 0, (hipStream_t)stream, src, ld,
+                     dst, (size_t)rows);
+  LAUNCH_CHECK();
+  return PRH_OK;
+}
+int prh_attn_fold_forward(const float* q, long ldq, const uint16_t* x16, const uint16_t* y16, const float* wk, long ldwk,
+                          const float* wv, long ldwv, const float* bv, float* o, long ldo, int B, int M, int N, int H,
+                          float scale, int device, void* stream) {
+  if (!q || !x16 || !y16 || !wk || !wv || !bv || !o || B <= 0 || M <= 0 || N <= 0)
+    return fail(PRH_ERR_ARG, "attn_fold_forward: bad argument");
+  if (H != 8 || M > 32) return fail(PRH_ERR_ARG, "attn_fold_forward: built for 8 heads of 32 channels and M <= 32 (H=%d M=%d)", H, M);
+  if ((ldq | ldo | ldwk | ldwv) & 3) return fail(PRH_ERR_ARG, "attn_fold_forward: leading dimensions must be multiples of 4");
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  AttnFoldParams a;
+  a.q = q; a.ldq = ldq; a.x16 = x16; a.y16 = y16; a.wk = wk; a.ldwk = ldwk; a.wv = wv; a.ldwv = ldwv; a.bv = bv;
+  a.o = o; a.ldo = ldo; a.B = B; a.M = M; a.N = N; a.H = H; a.scale = scale;
+  static const int attr = allow_big_lds(attn_fold_fwd_kernel);
+  if (attr != PRH_OK) return attr;
+  ProfScope ps("attn_fold_fwd", 2.0 * 2.0 * B * H * 32.0 * N * 256, 2.0 * 2.0 * B * (double)N * 256, st);
+  hipLaunchKernelGGL(attn_fold_fwd_kernel, dim3((unsigned)B), dim3(512), AF_LDS, st, a);
   LAUNCH_CHECK();
   return PRH_OK;
 }

@@ -27,6 +27,8 @@ multiples of 4, heads that are not 32 wide); the default model never takes it, a
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -219,7 +221,12 @@ class DetrTransformerDecoderLayer(nn.Module):
         ca = self.cross_attn
         qp = _lin(self.with_pos_embed(tgt, query_pos), ca.in_proj_weight[:d], ca.in_proj_bias[:d])
         pdrop = ca.dropout if self.training else 0.0
-        if kv_block is not None:      # k_proj / v_proj are the wide buffers, kv_block picks the block
+        if kv_block is not None and kv_block[0] == "fold":
+            # inference: attention over the raw memory rows, this layer's key / value projections
+            # folded into the kernel (k_proj / v_proj are the bf16 row images of memory + pos / memory)
+            o = ops.attention_folded(qp, k_proj, v_proj, ca.in_proj_weight[d:2 * d], ca.in_proj_weight[2 * d:],
+                                     ca.in_proj_bias[2 * d:], h)
+        elif kv_block is not None:      # k_proj / v_proj are the wide buffers, kv_block picks the block
             token, arena, blk = kv_block
             seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if pdrop > 0.0 else 0
             o = ops.attention_block(qp, k_proj, v_proj, token, arena, blk, h, pdrop, seed)
@@ -289,6 +296,15 @@ class LineRefineNet(nn.Module):
                           training=self.training, momentum=pm[1].momentum, eps=pm[1].eps)
         return y.reshape(B, M, -1)
 
+    fold_kv_inference = True      # False: reduced-precision inference keeps the K / V projection GEMMs
+
+    def _fold_ok(self, memory, noisy_line):
+        """Folded cross-attention: eval mode without autograd, on the GPU, in the reduced-precision
+        GEMM mode (io.refine_scene(precision="fp16"), bench --gemm bf16), reference widths."""
+        return (self.fold_kv_inference and not self.training and not torch.is_grad_enabled() and memory.is_cuda
+                and ops.bf16_mode() and self.d_model == 256 and noisy_line.shape[1] <= 32
+                and self.decoder_layers[0].cross_attn.num_heads == 8 and os.environ.get("PRH_ATTN_FOLD") != "0")
+
     def decode(self, context, noisy_line, memory, tgt):
         """Iterative refinement (src/model.py:197-234) given memory (B,N,256) and the initial
         queries tgt (B,M,256).  No BatchNorm in here, so it may be run on batch chunks.
@@ -301,12 +317,21 @@ class LineRefineNet(nn.Module):
         d = self.d_model
         layers = self.decoder_layers
         mempos = self.pos_emb(context[:, :, :3], resid=memory)      # memory + pos_mem, (B, N, 256)
+        fold = self._fold_ok(memory, noisy_line)
+        if fold:
+            # reduced-precision inference (BASELINE config 5): no K / V projection at all - every
+            # layer attends over the raw rows of memory + pos and memory with its projections
+            # folded into the kernel (csrc/prh_attnfold.hpp); the images are made once
+            k_all, v_all = ops.cast_perm_bf16(mempos), ops.cast_perm_bf16(memory)
         cat = ops.cat_rows if memory.is_cuda else torch.cat
-        wk = cat([l.cross_attn.in_proj_weight[d:2 * d] for l in layers])
-        bk = cat([l.cross_attn.in_proj_bias[d:2 * d] for l in layers])
-        wv = cat([l.cross_attn.in_proj_weight[2 * d:] for l in layers])
-        bv = cat([l.cross_attn.in_proj_bias[2 * d:] for l in layers])
-        if ops.bf16_mode() and mempos.is_cuda:
+        if not fold:
+            wk = cat([l.cross_attn.in_proj_weight[d:2 * d] for l in layers])
+            bk = cat([l.cross_attn.in_proj_bias[d:2 * d] for l in layers])
+            wv = cat([l.cross_attn.in_proj_weight[2 * d:] for l in layers])
+            bv = cat([l.cross_attn.in_proj_bias[2 * d:] for l in layers])
+        if fold:
+            pass
+        elif ops.bf16_mode() and mempos.is_cuda:
             # bf16 mode (BASELINE config 3): the wide K / V buffers and their gradients live in bf16
             k_all = ops.linear_out16(mempos, wk, bk)                # (B, N, 6*256) bf16
             v_all = ops.linear_out16(memory, wv, bv)
@@ -314,7 +339,9 @@ class LineRefineNet(nn.Module):
             k_all = ops.linear(mempos, wk, bk)                      # (B, N, 6*256)
             v_all = ops.linear(memory, wv, bv)
         fused = k_all.is_cuda and d == 256
-        if fused:
+        if fold:
+            token = arena = None
+        elif fused:
             # the fused attention kernels read column block i of k_all / v_all in place and
             # write dK / dV straight into one gradient buffer each (ops.GradArena): no
             # per-layer K/V tensors, no concatenation of their gradients
@@ -326,7 +353,9 @@ class LineRefineNet(nn.Module):
         all_pred_offsets = []
         for i, (decoder_layer, reg_branch) in enumerate(zip(layers, self.reg_branches)):
             pos_tgt = self.pos_emb(current_line_coords)
-            if fused:
+            if fold:
+                tgt = decoder_layer.forward_projected(tgt, k_all, v_all, query_pos=pos_tgt, kv_block=("fold", None, i))
+            elif fused:
                 tgt = decoder_layer.forward_projected(tgt, k_all, v_all, query_pos=pos_tgt,
                                                       kv_block=(token, arena, i))
             else:

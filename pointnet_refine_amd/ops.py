@@ -7,6 +7,7 @@ tensors - there is no CPU or eager fallback.
 from __future__ import annotations
 
 import ctypes as C
+import math
 from typing import List, Optional, Sequence
 
 import torch
@@ -1076,6 +1077,47 @@ def attention_block(q, k_all, v_all, token, arena, block_index: int, heads: int,
     ((B,N,n*C), contiguous); their gradients are assembled in the arena (see kv_token)."""
     return AttentionFn.apply(q, k_all.detach(), v_all.detach(), heads, dropout_p, seed, token, arena,
                              block_index)
+
+
+def cast_perm_bf16(x):
+    """(.., 256) fp32 rows -> the bf16 row image `attention_folded` reads (channels permuted inside
+    groups of 16, csrc/prh_attnfold.hpp); returned as an opaque (rows, 256) bfloat16 tensor."""
+    _req_gpu_f32(x, "memory rows")
+    if x.shape[-1] != 256:
+        raise RuntimeError("cast_perm_bf16: rows of 256 channels expected")
+    x2 = x.reshape(-1, 256)
+    if x2.stride(-1) != 1 or x2.stride(0) % 4:
+        x2 = x2.contiguous()
+    out = torch.empty((x2.shape[0], 256), dtype=torch.bfloat16, device=x.device)
+    L.check(L.lib().prh_cast_perm_bf16(_p(x2), x2.stride(0), _p(out), x2.shape[0], x.device.index, _stream(x.device)),
+            "prh_cast_perm_bf16")
+    return out
+
+
+def attention_folded(q, x16, y16, wk, wv, bv, heads: int):
+    """Inference-only cross-attention with the key / value projections folded in
+    (src/model.py:119-128 in eval mode): q (B,M,256) projected queries, x16 / y16 = cast_perm_bf16 of
+    memory + pos and of memory ((B*N, 256)), wk / wv (256,256) and bv (256) the key / value rows of the
+    layer's packed in_proj parameters.  Returns the (B,M,256) attention output before out_proj.  No
+    autograd; 8 heads of 32 channels, M <= 32, bf16 products (BASELINE config 5)."""
+    _req_gpu_f32(q, "queries")
+    B, M, Cq = q.shape
+    if Cq != 256 or heads != 8 or M > 32:
+        raise RuntimeError("attention_folded: 8 heads of 32 channels and at most 32 queries")
+    if torch.is_grad_enabled() and (q.requires_grad or wk.requires_grad):
+        raise RuntimeError("attention_folded is inference-only: call it under torch.no_grad()")
+    N = x16.shape[0] // B
+    if x16.shape != y16.shape or x16.shape[0] != B * N or x16.dtype != torch.bfloat16:
+        raise RuntimeError("attention_folded: x16 / y16 must be cast_perm_bf16 images of (B*N, 256) rows")
+    q2 = q.reshape(B * M, 256)
+    if not q2.is_contiguous():
+        q2 = q2.contiguous()
+    wk, wv, bv = wk.contiguous(), wv.contiguous(), bv.contiguous()
+    o = torch.empty((B * M, 256), dtype=torch.float32, device=q.device)
+    L.check(L.lib().prh_attn_fold_forward(_p(q2), 256, _p(x16), _p(y16), _p(wk), wk.stride(0), _p(wv), wv.stride(0),
+                                          _p(bv), _p(o), 256, B, M, N, heads, 1.0 / math.sqrt(32.0), q.device.index,
+                                          _stream(q.device)), "prh_attn_fold_forward")
+    return o.view(B, M, 256)
 
 
 def attention_keep_mask(B, H, M, N, dropout_p, seed, device="cpu"):
