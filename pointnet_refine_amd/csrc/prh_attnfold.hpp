@@ -32,10 +32,18 @@
 namespace prh {
 
 typedef unsigned short u16_t;
-constexpr int AF_ROW = 512;                 // bytes per key row: 256 bf16
-constexpr int AF_TILE = 32 * AF_ROW;        // 16 KB
-constexpr int AF_STAGE = 2 * AF_TILE;       // X tile | Y tile
-constexpr int AF_LDS = 3 * AF_STAGE;        // 96 KB: three stages, one barrier per tile
+// LDS tiles of 32 keys x 256 bf16 channels.  Rows are PADDED rather than XOR-swizzled, so that every
+// fragment address is one per-lane base plus a compile-time offset (the XOR form cost ~100 address
+// instructions per tile and still left 2-way conflicts on the transposed reads: 0.32 conflict
+// cycles per active LDS cycle, measured):
+//   X (row-on-the-lane 16-B reads: 16 lanes = 16 rows, same chunk):  528-B rows -> bank group 4 (row + chunk)
+//   Y (transposed 8-B reads: 4 rows x 4 chunks per 32 lanes):         576-B rows -> bank group 4 (4 row + chunk)
+// A padded row is not contiguous with its neighbour, so one LDS-DMA instruction carries one row
+// (lanes 0..31, 512 B).
+constexpr int AF_XROW = 528, AF_YROW = 576;
+constexpr int AF_XTILE = 32 * AF_XROW, AF_YTILE = 32 * AF_YROW;
+constexpr int AF_STAGE = AF_XTILE + AF_YTILE;            // 35,328 B
+constexpr int AF_LDS = 3 * AF_STAGE;                     // three stages, one barrier per tile
 
 // fp32 [rows][256] (ld) -> bf16 [rows][256], channel p of the output = channel swap23(p) of the input
 __global__ __launch_bounds__(256) void cast_perm_b16_kernel(const float* __restrict__ src, long ld,
@@ -76,19 +84,18 @@ __global__ __launch_bounds__(512, 2) void attn_fold_fwd_kernel(const AttnFoldPar
   const int b = blockIdx.x;
   const unsigned lds0 = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)smem);
 
-  // key tiles: 32 pieces of 1 KB per stage (16 per tensor: 2 rows each), 4 per wave
+  // key tiles: 64 rows per stage (32 of X, 32 of Y), 8 per wave, one row per DMA instruction
   auto dma = [&](int k0, int stage) {
+    if (lane < 32) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int pc = __builtin_amdgcn_readfirstlane(h * 4 + i);
-      const int row = 2 * (pc & 15) + h2;
-      int key = k0 + row;
-      key = key < p.N ? key : p.N - 1;
-      // X: chunk ^ row (the 16 lanes of a row-read quarter hit 16 different chunks); Y: chunk ^ 2 row (the
-      // transposed reads take two adjacent chunks of four consecutive rows: eight different chunks)
-      const int sw = (pc >> 4) ? ((row << 1) & 31) : (row & 31);
-      const u16_t* src = ((pc >> 4) ? p.y16 : p.x16) + ((size_t)b * p.N + key) * 256 + ((l31 ^ sw) << 3);
-      glds16(src, lds0 + stage * AF_STAGE + (pc >> 4) * AF_TILE + (pc & 15) * 1024);
+      for (int i = 0; i < 8; ++i) {
+        const int pc = __builtin_amdgcn_readfirstlane(h * 8 + i);
+        const int row = pc & 31;
+        int key = k0 + row;
+        key = key < p.N ? key : p.N - 1;
+        const u16_t* src = ((pc >> 5) ? p.y16 : p.x16) + ((size_t)b * p.N + key) * 256 + (lane << 3);
+        glds16(src, lds0 + stage * AF_STAGE + ((pc >> 5) ? AF_XTILE + row * AF_YROW : row * AF_XROW));
+      }
     }
   };
   dma(0, 0);
@@ -135,21 +142,20 @@ __global__ __launch_bounds__(512, 2) void attn_fold_fwd_kernel(const AttnFoldPar
   // publishes tile kt also says every wave is done with tile kt-1, whose stage takes tile kt+2
   int stage = 0;
   for (int k0 = 0; k0 < p.N; k0 += 32) {
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // this wave's pieces of tile kt (tile kt+1 may fly)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // this wave's rows of tile kt (tile kt+1 may fly)
     __syncthreads();
     dma(k0 + 64, stage == 0 ? 2 : stage - 1);
     const char* xt = smem + stage * AF_STAGE;
-    const char* yt = xt + AF_TILE;
+    const char* yt = xt + AF_XTILE;
     // S^T[key][q]
     f32x16 s = a16_zero();
     {
-      const char* xr = xt + l31 * AF_ROW;
+      const char* xr = xt + l31 * AF_XROW + h2 * 16;
 #pragma unroll
       for (int cb = 0; cb < 8; ++cb)
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
-          const int c = cb * 4 + 2 * st + h2;
-          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(xr + ((c ^ l31) << 4));
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(xr + cb * 64 + st * 32);
           s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[cb][st], s, 0, 0, 0);
         }
     }
@@ -184,17 +190,13 @@ __global__ __launch_bounds__(512, 2) void attn_fold_fwd_kernel(const AttnFoldPar
     a16_acc_frag<1>(s, 1, pf[1]);
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
-      const int row = 16 * st + 4 * (g >> 1) + (jj >> 2);
-      const char* yr0 = yt + row * AF_ROW;
-      const char* yr1 = yr0 + 8 * AF_ROW;
+      // lane -> (key row 16 st + 4 (g >> 1) + (jj >> 2), four channels at 16 (g & 1) + 4 (jj & 3)) of a 32-channel block
+      const char* yr0 = yt + (16 * st + 4 * (g >> 1) + (jj >> 2)) * AF_YROW + (16 * (g & 1) + 4 * (jj & 3)) * 2;
 #pragma unroll
       for (int cb = 0; cb < 8; ++cb) {
-        const int col = cb * 32 + 16 * (g & 1) + 4 * (jj & 3);
-        const int ch = col >> 3, off = (col & 7) * 2;
-        const fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-            (__attribute__((address_space(3))) fp16x4*)(yr0 + ((ch ^ ((row << 1) & 31)) << 4) + off));
+        const fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(yr0 + cb * 64));
         const fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-            (__attribute__((address_space(3))) fp16x4*)(yr1 + ((ch ^ (((row + 8) << 1) & 31)) << 4) + off));
+            (__attribute__((address_space(3))) fp16x4*)(yr0 + cb * 64 + 8 * AF_YROW));
         struct Pair { fp16x4 a, b; } pr = {lo, hi};
         const bf16x8 ya = __builtin_bit_cast(bf16x8, pr);
         py[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ya, pf[st][0], py[cb], 0, 0, 0);
