@@ -12,7 +12,7 @@
 // by vector-instruction issue, not by the matrix pipe.
 //
 // One workgroup = one segment, its 8 waves = the 8 heads.  A tile of 32 keys of X and of Y
-// (bf16, [32][256], LDS-DMA, double buffered) is shared by the 8 heads.  Per head:
+// (bf16, [32][256], LDS-DMA, three stages, one barrier per tile) is shared by the 8 heads.  Per head:
 //   prologue  Q'^T[c][q] = sum_d Wk[h 32 + d][c] Q_h[q][d]       (8 blocks of 32 channels; kept as
 //             bf16 B-operand fragments: 64 registers)
 //   per tile  S^T[key][q] = sum_c X[key][c] Q'^T[c][q]            16 MFMAs 32x32x16
