@@ -525,7 +525,7 @@ def run(args):
             line["parity"] = parity
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, args.cpu_batch)
-        print(json.dumps(line), flush=True)
+        emit(line)
     if launched:
         dist.destroy_process_group()
     if parity_failed:
@@ -636,16 +636,41 @@ def run_encoder(args):
                        "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 4),
                        "note": "compulsory traffic only (context in, fused + global_feat out): the kernel is bound "
                                "by the matrix pipe and L2 weight streaming, not by HBM (SURVEY D8)"}
-    print(json.dumps(line), flush=True)
+    emit(line)
     return 0
+
+
+_RESULT_FD = None
+
+
+def quiet_stdout():
+    """stdout carries ONE JSON line.  Libraries write to file descriptor 1 behind Python's back
+    (this RCCL build prints a three-line banner - ROCm version, hostname, library path - when the
+    first communicator is made), so fd 1 is pointed at stderr for the whole run and the result
+    line goes to a saved copy of the original descriptor."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line):
+    data = (json.dumps(line) + "\n").encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_RESULT_FD, data)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ and not args.encoder_only:
+        return launch_ranks(args)      # the ranks' own stdout passes through: rank 0 prints the line
+    quiet_stdout()
     if args.encoder_only:
         return run_encoder(args)
-    if args.gpus > 1 and "RANK" not in os.environ:
-        return launch_ranks(args)
     return run(args)
 
 
