@@ -107,7 +107,7 @@ __global__ __launch_bounds__(512, 2) void attn_fold_fwd_kernel(const AttnFoldPar
     float xq[16];
     a16_load_rows(p.q, p.ldq, (long)b * p.M, p.M, h * 32, lane, xq);
 #pragma unroll
-    for (int t = 0; t < 16; ++t) xq[t] *= p.scale;
+    for (int t = 0; t < 16; ++t) xq[t] *= p.scale * 1.4426950408889634f;      // scores in units of log2 e
     float t0[8], t1[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { t0[j] = xq[j]; t1[j] = xq[8 + j]; }
@@ -159,19 +159,21 @@ __global__ __launch_bounds__(512, 2) void attn_fold_fwd_kernel(const AttnFoldPar
           s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[cb][st], s, 0, 0, 0);
         }
     }
+    // scores arrive in units of log2 e (folded into the query scale): exp2 is one instruction
+    if (k0 + 32 > p.N) {      // last, partial tile only
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = (k0 + crow(r, h2) >= p.N) ? -INFINITY : s[r];
+    }
     float mx = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      s[r] = (k0 + crow(r, h2) >= p.N) ? -INFINITY : s[r];
-      mx = fmaxf(mx, s[r]);
-    }
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = __expf(m_run - m_new);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     float psum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float e = __expf(s[r] - m_new);
+      const float e = __builtin_amdgcn_exp2f(s[r] - m_new);
       psum += e;
       s[r] = e;
     }
