@@ -163,6 +163,12 @@ int prh_linear_backward_bf16(const uint16_t* x, long ldx, const float* w, const 
  * of the layer's packed in_proj parameters, o [B*M, 256] (before out_proj).  8 heads of 32 channels,
  * M <= 32, bf16 products with fp32 accumulation (BASELINE config 5). */
 int prh_cast_perm_bf16(const float* src, long ld, uint16_t* dst, long rows, int device, void* stream);
+/* ... or both images in one pass from their sources: x16 = bf16(memory + pos), y16 = bf16(memory) with
+ * pos = PositionalEncoding(xyz) = relu(xyz W0^T + b0) W2^T + b2 (src/model.py:64-75; W0 [256,3], W2 [256,256]).
+ * The hidden layer and memory + pos never exist in fp32: 2 KB per point instead of 7 (pos_hidden, Linear
+ * with residual, two casts).  xyz rows read in place (ld >= 3), memory [rows, 256] (ld >= 256). */
+int prh_posmem_images(const float* xyz, long ldx, const float* w0, const float* b0, const float* w2, const float* b2,
+                      const float* memory, long ldm, long rows, uint16_t* x16, uint16_t* y16, int device, void* stream);
 int prh_attn_fold_forward(const float* q, long ldq, const uint16_t* x16, const uint16_t* y16, const float* wk, long ldwk,
                           const float* wv, long ldwv, const float* bv, float* o, long ldo, int B, int M, int N, int H,
                           float scale, int device, void* stream);

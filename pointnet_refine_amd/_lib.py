@@ -78,7 +78,7 @@ EXPORTS = [
     "prh_l1_loss_workspace_bytes", "prh_l1_loss", "prh_adam_step",
     "prh_add_dropout_layernorm_forward", "prh_add_dropout_layernorm_workspace_bytes",
     "prh_add_dropout_layernorm_backward",
-    "prh_relu_mask_absmax", "prh_cast_perm_bf16", "prh_attn_fold_forward", "prh_set_gemm_mode", "prh_get_gemm_mode", "prh_set_dropout_seed_source",
+    "prh_relu_mask_absmax", "prh_cast_perm_bf16", "prh_posmem_images", "prh_attn_fold_forward", "prh_set_gemm_mode", "prh_get_gemm_mode", "prh_set_dropout_seed_source",
     "prh_last_error", "prh_version",
 ]
 
@@ -218,6 +218,8 @@ def _bind(lib):
     lib.prh_adam_step.argtypes = [vp, vp, vp, vp, lg, f, f, f, f, f, i, i, vp]
     lib.prh_cast_perm_bf16.restype = i
     lib.prh_cast_perm_bf16.argtypes = [vp, lg, vp, lg, i, vp]
+    lib.prh_posmem_images.restype = i
+    lib.prh_posmem_images.argtypes = [vp, lg, vp, vp, vp, vp, vp, lg, lg, vp, vp, i, vp]
     lib.prh_attn_fold_forward.restype = i
     lib.prh_attn_fold_forward.argtypes = [vp, lg, vp, vp, vp, lg, vp, lg, vp, vp, lg, i, i, i, i, C.c_float, i, vp]
     lib.prh_relu_mask_absmax.restype = i

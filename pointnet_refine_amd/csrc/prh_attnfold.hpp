@@ -61,6 +61,103 @@ __global__ __launch_bounds__(256) void cast_perm_b16_kernel(const float* __restr
   o[1] = hi;      // positions 8..15 = channels 4..7, 12..15
 }
 
+__device__ __forceinline__ bf16x8 af_pack(const float (&f)[8]) {
+  const uint4 u = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+  return __builtin_bit_cast(bf16x8, u);
+}
+
+// The two row images the folded attention reads, straight from their sources (inference): for every
+// context point  pos = relu(xyz W0^T + b0) W2^T + b2  (PositionalEncoding, src/model.py:64-75),
+//   x16 = bf16(memory + pos),  y16 = bf16(memory)        (channel order of cast_perm_b16_kernel).
+// Replaces pos_hidden + the 256 x 256 Linear with its residual epilogue + two casts: the hidden
+// layer never exists in memory (each lane generates the 8 values of its point a k-step needs),
+// memory + pos never exists in fp32, and memory is read once: 2 KB per point instead of 7.
+// Persistent workgroups of 8 waves; W2 is converted to bf16 into LDS once per workgroup
+// ([256 n][256 k], rows padded to 528 B); a wave owns 32 points per pass: 16 k-steps x 8 column
+// blocks of v_mfma_f32_32x32x16_bf16 with the point on the lane, then the epilogue reads memory and
+// writes both images in 16-B runs.
+constexpr int PM_WROW = 528;                               // bytes per W2 row in LDS
+constexpr int PM_LDS = 256 * PM_WROW + 256 * 16;           // + (w0x, w0y, w0z, b0) per hidden unit
+
+__global__ __launch_bounds__(512, 2) void posmem_images_kernel(const float* __restrict__ xyz, long ldx,
+                                                               const float* __restrict__ w0, const float* __restrict__ b0,
+                                                               const float* __restrict__ w2, const float* __restrict__ b2,
+                                                               const float* __restrict__ mem, long ldm, long P,
+                                                               u16_t* __restrict__ x16, u16_t* __restrict__ y16) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h2 = lane >> 5, l31 = lane & 31;
+  float4* tab = reinterpret_cast<float4*>(smem + 256 * PM_WROW);
+  // W2 [n][k] fp32 -> bf16 rows in LDS; the first-layer table
+  for (int i = tid; i < 256 * 32; i += 512) {              // item = (row n, chunk of 8 k)
+    const int n = i >> 5, c = i & 31;
+    const float* q = w2 + (size_t)n * 256 + c * 8;
+    const float4 a = ldg4(q), b = ldg4(q + 4);
+    *reinterpret_cast<uint4*>(smem + n * PM_WROW + c * 16) =
+        make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
+  }
+  if (tid < 256) tab[tid] = make_float4(w0[tid * 3], w0[tid * 3 + 1], w0[tid * 3 + 2], b0 != nullptr ? b0[tid] : 0.f);
+  __syncthreads();
+
+  const long tiles = (P + 255) / 256;
+  for (long t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const long p0 = t * 256 + wave * 32;
+    if (p0 >= P) continue;                                  // (no barrier below: a wave may skip)
+    const long pr = p0 + l31 < P ? p0 + l31 : P - 1;
+    const float px = xyz[pr * ldx], py_ = xyz[pr * ldx + 1], pz = xyz[pr * ldx + 2];
+    f32x16 acc[8];
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) acc[nb] = a16_zero();
+#pragma unroll 2
+    for (int s = 0; s < 16; ++s) {
+      // A[row = point][k = 16 s + 8 h2 + j]: the hidden layer of this lane's point
+      float hv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float4 c = tab[16 * s + 8 * h2 + j];
+        hv[j] = fmaxf(fmaf(pz, c.z, fmaf(py_, c.y, fmaf(px, c.x, c.w))), 0.f);
+      }
+      const bf16x8 hf = af_pack(hv);
+      const char* wr = smem + l31 * PM_WROW + (16 * s + 8 * h2) * 2;
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb) {
+        // pos^T[n][point] = sum_k W2[n][k] h[point][k]: A = W2 rows (lane n = 32 nb + l31), B = the hidden
+        // layer with the POINT on the lane - so that a lane ends up with 16-B runs of its own row
+        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wr + nb * 32 * PM_WROW);
+        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, hf, acc[nb], 0, 0, 0);
+      }
+    }
+    // D[row = n = 32 nb + crow(r, h2)][col = point]: registers 8q'..8q'+7 (q' = 0, 1) are channels
+    // 16 q' + 4 h2 + {0..3} and 16 q' + 8 + 4 h2 + {0..3} = image positions 16 q' + 8 h2 + {0..7}: one
+    // 16-B store per image, two float4 loads of memory
+    const long pt = p0 + l31;
+    if (pt < P) {
+      const float* mrow = mem + pt * ldm + 4 * h2;
+      u16_t* xrow = x16 + pt * 256 + 8 * h2;
+      u16_t* yrow = y16 + pt * 256 + 8 * h2;
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+          const int n0 = nb * 32 + 16 * qq;
+          const float4 m0 = ldg4(mrow + n0), m1 = ldg4(mrow + n0 + 8);
+          float4 c0 = zero4(), c1 = zero4();
+          if (b2 != nullptr) { c0 = ldg4(b2 + n0 + 4 * h2); c1 = ldg4(b2 + n0 + 8 + 4 * h2); }
+          const f32x16& a = acc[nb];
+          const int r0 = 8 * qq;
+          const uint4 xo = make_uint4(pack_bf16x2(m0.x + a[r0] + c0.x, m0.y + a[r0 + 1] + c0.y),
+                                      pack_bf16x2(m0.z + a[r0 + 2] + c0.z, m0.w + a[r0 + 3] + c0.w),
+                                      pack_bf16x2(m1.x + a[r0 + 4] + c1.x, m1.y + a[r0 + 5] + c1.y),
+                                      pack_bf16x2(m1.z + a[r0 + 6] + c1.z, m1.w + a[r0 + 7] + c1.w));
+          const uint4 yo = make_uint4(pack_bf16x2(m0.x, m0.y), pack_bf16x2(m0.z, m0.w), pack_bf16x2(m1.x, m1.y),
+                                      pack_bf16x2(m1.z, m1.w));
+          *reinterpret_cast<uint4*>(xrow + n0) = xo;
+          *reinterpret_cast<uint4*>(yrow + n0) = yo;
+        }
+    }
+  }
+}
+
 struct AttnFoldParams {
   const float* q; long ldq;          // [B*M, H*32] projected queries
   const u16_t* x16; const u16_t* y16;   // [B*N, 256] bf16, channel-permuted: memory + pos, memory
@@ -71,11 +168,6 @@ struct AttnFoldParams {
   int B, M, N, H;
   float scale;
 };
-
-__device__ __forceinline__ bf16x8 af_pack(const float (&f)[8]) {
-  const uint4 u = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
-  return __builtin_bit_cast(bf16x8, u);
-}
 
 __global__ __launch_bounds__(512, 2) void attn_fold_fwd_kernel(const AttnFoldParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];

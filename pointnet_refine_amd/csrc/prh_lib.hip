@@ -2361,6 +2361,31 @@ int prh_cast_perm_bf16(const float* src, long ld, uint16_t* dst, long rows, int 
   LAUNCH_CHECK();
   return PRH_OK;
 }
+/* Both row images of the folded attention from their sources in one pass (csrc/prh_attnfold.hpp):
+ * x16 = bf16(memory + pos_emb(xyz)), y16 = bf16(memory) with pos_emb = Linear(3,256) + ReLU + Linear(256,256)
+ * (src/model.py:64-75).  xyz rows are read in place (ld >= 3), memory [rows, 256] (ld >= 256). */
+int prh_posmem_images(const float* xyz, long ldx, const float* w0, const float* b0, const float* w2, const float* b2,
+                      const float* memory, long ldm, long rows, uint16_t* x16, uint16_t* y16, int device, void* stream) {
+  if (!xyz || !w0 || !w2 || !memory || !x16 || !y16 || rows < 0 || ldx < 3 || ldm < 256)
+    return fail(PRH_ERR_ARG, "posmem_images: bad argument");
+  HIP_TRY(hipSetDevice(device));
+  if (rows == 0) return PRH_OK;
+  static const int attr = allow_big_lds(posmem_images_kernel);
+  if (attr != PRH_OK) return attr;
+  static const int n_cu = [] {
+    int dev = 0, cu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
+    return cu > 0 ? cu : 256;
+  }();
+  const long tiles = (rows + 255) / 256;
+  const unsigned grid = (unsigned)(tiles < n_cu ? tiles : n_cu);
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps("posmem_images", 2.0 * rows * 256.0 * 256.0, (double)rows * (16.0 + 1024.0 + 1024.0), st);
+  hipLaunchKernelGGL(posmem_images_kernel, dim3(grid), dim3(512), PM_LDS, st, xyz, ldx, w0, b0, w2, b2, memory, ldm, rows,
+                     x16, y16);
+  LAUNCH_CHECK();
+  return PRH_OK;
+}
 int prh_attn_fold_forward(const float* q, long ldq, const uint16_t* x16, const uint16_t* y16, const float* wk, long ldwk,
                           const float* wv, long ldwv, const float* bv, float* o, long ldo, int B, int M, int N, int H,
                           float scale, int device, void* stream) {

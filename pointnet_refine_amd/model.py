@@ -316,13 +316,20 @@ class LineRefineNet(nn.Module):
         GEMM cores instead of twelve library GEMMs plus six elementwise adds."""
         d = self.d_model
         layers = self.decoder_layers
-        mempos = self.pos_emb(context[:, :, :3], resid=memory)      # memory + pos_mem, (B, N, 256)
         fold = self._fold_ok(memory, noisy_line)
         if fold:
             # reduced-precision inference (BASELINE config 5): no K / V projection at all - every
             # layer attends over the raw rows of memory + pos and memory with its projections
-            # folded into the kernel (csrc/prh_attnfold.hpp); the images are made once
-            k_all, v_all = ops.cast_perm_bf16(mempos), ops.cast_perm_bf16(memory)
+            # folded into the kernel (csrc/prh_attnfold.hpp).  The two bf16 row images are made
+            # once, straight from the points and `memory` (the positional MLP runs inside that pass)
+            l0, l2 = self.pos_emb.mlp[0], self.pos_emb.mlp[2]
+            if tuple(l0.weight.shape) == (256, 3) and tuple(l2.weight.shape) == (256, 256):
+                k_all, v_all = ops.posmem_images(context[:, :, :3], memory, l0.weight, l0.bias, l2.weight, l2.bias)
+            else:
+                mempos = self.pos_emb(context[:, :, :3], resid=memory)
+                k_all, v_all = ops.cast_perm_bf16(mempos), ops.cast_perm_bf16(memory)
+        else:
+            mempos = self.pos_emb(context[:, :, :3], resid=memory)      # memory + pos_mem, (B, N, 256)
         cat = ops.cat_rows if memory.is_cuda else torch.cat
         if not fold:
             wk = cat([l.cross_attn.in_proj_weight[d:2 * d] for l in layers])

@@ -1094,6 +1094,33 @@ def cast_perm_bf16(x):
     return out
 
 
+def posmem_images(xyz, memory, w0, b0, w2, b2):
+    """The two row images `attention_folded` reads, in one pass from their sources (inference):
+    x16 = bf16(memory + pos_emb(xyz)), y16 = bf16(memory), pos_emb = Linear(3,256) + ReLU +
+    Linear(256,256) (src/model.py:64-75).  xyz (B,N,3) may be a view of wider rows (context[:, :, :3]);
+    memory (B,N,256).  Returns two (B*N, 256) bfloat16 tensors (opaque channel order)."""
+    _req_gpu_f32(xyz, "points")
+    _req_gpu_f32(memory, "memory")
+    if xyz.shape[-1] != 3 or memory.shape[-1] != 256 or tuple(w0.shape) != (256, 3) or tuple(w2.shape) != (256, 256):
+        raise RuntimeError("posmem_images: 3-wide points, 256-wide memory, Linear(3,256) and Linear(256,256) expected")
+    rows = memory.numel() // 256
+    ld = xyz.stride(-2) if xyz.dim() >= 2 else 3
+    ok = xyz.stride(-1) == 1 and ld >= 3 and xyz.numel() // 3 == rows
+    for d in range(xyz.dim() - 2):
+        ok = ok and xyz.stride(d) == xyz.stride(d + 1) * xyz.shape[d + 1]
+    if not ok:
+        xyz, ld = xyz.contiguous(), 3
+    m2 = memory.reshape(rows, 256)
+    if not m2.is_contiguous():
+        m2 = m2.contiguous()
+    x16 = torch.empty((rows, 256), dtype=torch.bfloat16, device=memory.device)
+    y16 = torch.empty_like(x16)
+    L.check(L.lib().prh_posmem_images(_p(xyz), ld, _p(w0.contiguous()), _p(b0), _p(w2.contiguous()), _p(b2), _p(m2), 256,
+                                      rows, _p(x16), _p(y16), memory.device.index, _stream(memory.device)),
+            "prh_posmem_images")
+    return x16, y16
+
+
 def attention_folded(q, x16, y16, wk, wv, bv, heads: int):
     """Inference-only cross-attention with the key / value projections folded in
     (src/model.py:119-128 in eval mode): q (B,M,256) projected queries, x16 / y16 = cast_perm_bf16 of

@@ -88,3 +88,28 @@ def test_g1_and_the_unfolded_path_through_the_model(golden_dir):
     assert maxdiff(out_fold, g["out"]) < 5e-2
     assert maxdiff(out_plain, g["out"]) < 5e-2
     assert maxdiff(out_fold, out_plain) < 3e-2
+
+
+@pytest.mark.parametrize("B,N", [(2, 100), (1, 1), (3, 256), (5, 777)])
+def test_posmem_images_match_the_separate_path(B, N):
+    """ops.posmem_images = pos_hidden + Linear(256,256) with the memory residual + the two casts, in
+    one pass: same images as the separate path up to bf16 rounding of the hidden layer."""
+    from pointnet_refine_amd import ops
+    g = torch.Generator().manual_seed(B + N)
+    ctx = torch.randn(B, N, 4, generator=g).cuda()
+    mem = torch.randn(B, N, 256, generator=g).cuda()
+    w0 = torch.randn(256, 3, generator=g).cuda()
+    b0 = torch.randn(256, generator=g).cuda()
+    w2 = (torch.randn(256, 256, generator=g) / 16).cuda()
+    b2 = torch.randn(256, generator=g).cuda()
+    with torch.no_grad():
+        x16, y16 = ops.posmem_images(ctx[:, :, :3], mem, w0, b0, w2, b2)
+        h = torch.relu(ctx[:, :, :3].double() @ w0.double().t() + b0.double())
+        mempos = mem.double() + h @ w2.double().t() + b2.double()
+        # the opaque channel order is the one cast_perm_bf16 produces
+        assert torch.equal(y16, ops.cast_perm_bf16(mem))
+        want = ops.cast_perm_bf16(mempos.float()).float()
+    got = x16.float()
+    assert got.shape == (B * N, 256)
+    assert rel_l2(want, got) < 1e-2          # bf16 hidden layer and weights, fp32 accumulation
+    assert maxdiff(got, want) < 0.05 * float(want.abs().max())
