@@ -79,6 +79,8 @@ def parse():
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of the fused flat-buffer Adam")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the exact-fp32 parity step after the timed region")
+    ap.add_argument("--no-workloads", action="store_true",
+                    help="skip the `workloads` object (the other BASELINE.json configs, run after the timed region)")
     ap.add_argument("--kernels", type=int, default=0, help="print the K longest GEMM launches (live HIP-event times) to stderr")
     ap.add_argument("--cpu-batch", type=int, default=16,
                     help="segments in the CPU sample (16: the host's best throughput; 64 measured 2.5x slower per segment)")
@@ -86,9 +88,6 @@ def parse():
                     help="second workload (not the headline metric): MultiScalePointNetEncoder.forward returning "
                          "(global_feat, fused) - the north_star's fused shared-MLP + max-pool - alone: train-mode "
                          "forward+backward, or with --eval the inference forward through the single fused kernel")
-    ap.add_argument("--pool", action="store_true",
-                    help="with --encoder-only: accepted for the command line the round-1 review names "
-                         "(`--encoder-only --pool`); the dual max + mean pooling is always part of that workload")
     ap.add_argument("--eval", action="store_true", help="with --encoder-only: eval-mode forward only (fused kernel)")
     ap.add_argument("--stub", action="store_true",
                     help="launcher self-test: a small CPU stand-in model over the gloo backend instead of "
@@ -186,11 +185,15 @@ def cpu_baseline(points, batch):
 
 
 def kernel_sources_sha():
-    """Same fingerprint as scripts/pmc_traffic.py records next to the counters."""
+    """Fingerprint of EVERY file of csrc/ (the file set _lib._SOURCES compiles); scripts/pmc_traffic.py
+    records the same value next to the counters."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("prh_gemm.hpp", "prh_gemm_s3.hpp", "prh_gemm_h2.hpp", "prh_b16.hpp", "prh_attn16.hpp", "prh_fused.hpp"):
-        h.update(open(os.path.join(ROOT, "pointnet_refine_amd", "csrc", f), "rb").read())
+    d = os.path.join(ROOT, "pointnet_refine_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hpp", ".h", ".hip")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -260,15 +263,18 @@ class StubNet:
         return Tiny()
 
 
-def parity_check(step, model, batch, lib, mode, dev):
+def parity_check(step, model, batch, lib, mode, dev, batch_bench=None, vhat=None):
     """One step at the benchmark size with the benchmarked GEMM cores and one with the exact-fp32
     MFMA cores: same inputs, same weights and BatchNorm buffers, same dropout seeds (the hash
-    masks are functions of seeds drawn from torch's CPU generator).  No optimiser step."""
+    masks are functions of seeds drawn from torch's CPU generator).  No optimiser step.  vhat: Adam's
+    bias-corrected second-moment estimate, laid out like the flat gradient buffer - when given, every
+    tensor also gets the RMS of (g_bench - g_exact) / (sqrt(vhat) + 1e-8): the error of the parameter
+    update this gradient would cause, in units of the learning rate."""
     import torch
     from pointnet_refine_amd import ops
     snap = {k: v.detach().clone() for k, v in model.state_dict().items()}
     names = [n for n, p in model.named_parameters() if p.requires_grad]
-    res = {}
+    res, ms = {}, {}
     step.keep_out = True
     try:
         for tag, m in (("bench", mode), ("exact", 0)):
@@ -278,8 +284,11 @@ def parity_check(step, model, batch, lib, mode, dev):
                     v.copy_(snap[k])
             torch.manual_seed(20240217)
             step.grads.zero()
-            loss = step.forward_backward(*batch)
             torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            loss = step.forward_backward(*(batch_bench if (tag == "bench" and batch_bench is not None) else batch))
+            torch.cuda.synchronize(dev)
+            ms[tag] = (time.perf_counter() - t0) * 1e3
             res[tag] = (step.last_out.clone(), step.grads.flat.clone(), float(loss))
             step.last_out = None
             ops.release_workspaces()
@@ -296,20 +305,224 @@ def parity_check(step, model, batch, lib, mode, dev):
     worst, worst_name, off = 0.0, "", 0
     gmax = 0.0
     per = []
-    for n, p in zip(names, step.grads.params):
+    for n, p, o in zip(names, step.grads.params, step.grads.offsets):
         k = p.numel()
-        a, b = ga[off:off + k].double(), gb[off:off + k].double()
-        off += k
-        per.append((n, float(b.norm()), float((a - b).norm())))
+        off = o + k
+        a, b = ga[o:off].double(), gb[o:off].double()
+        upd = None
+        if vhat is not None:
+            d = vhat[off - k:off].double().sqrt() + 1e-8
+            upd = float(((a - b) / d).square().mean().sqrt())
+        per.append((n, float(b.norm()), float((a - b).norm()), upd))
         gmax = max(gmax, per[-1][1])
-    for n, bn, dn in per:
+    for n, bn, dn, _ in per:
         if bn > 1e-7 * gmax and bn > 0:          # tensors that receive a gradient at all
             r = dn / bn
             if r > worst:
                 worst, worst_name = r, n
     total = float((ga.double() - gb.double()).norm() / (gb.double().norm() + 1e-30))
     return {"out_max_abs_vs_exact_fp32": out_err, "out_rel_l2_vs_exact_fp32": out_rel, "worst_grad_rel_l2": worst, "worst_grad": worst_name,
-            "all_grads_rel_l2": total, "loss": la, "loss_exact_fp32": lb}
+            "all_grads_rel_l2": total, "loss": la, "loss_exact_fp32": lb, "per_tensor": per,
+            "fwd_bwd_ms": round(ms["bench"], 2), "exact_fp32_fwd_bwd_ms": round(ms["exact"], 2)}
+
+
+GRAD_BOUND_REDUCED = 1e-1      # reduced-precision modes: per-tensor gradient rel-L2 against the exact-fp32 cores
+GRAD_BOUND_FP32 = 2e-3         # fp32-accurate modes (1e-3; ReLU / arg-max flips inside fp32 noise add O(1e-3))
+UPDATE_BOUND = 1e-1            # reduced precision, trained state: RMS Adam-update error per tensor, in units of lr
+
+
+def grade_parity(parity, mode, at_init=None):
+    """Turns parity_check's record into the gated `parity` object of the bench line: EVERY tensor
+    that receives a gradient (norm above 1e-7 of the largest tensor's) is held to a per-tensor bound,
+    not only the outputs.
+
+    fp32-accurate modes: rel-L2 <= 2e-3 per tensor at the benchmarked (trained) state.
+    Reduced precision (bf16 mode): a forward rounded to 8 bits moves the point at which the gradient
+    is evaluated, which costs an ABSOLUTE gradient error that does not shrink with the gradient
+    (profiles/r03b_bf16_grad_budget.txt: the encoder's gradients fall 200-500x over the first 25 Adam
+    steps of the benchmark, their absolute error 3x) - so rel-L2 against a vanishing gradient is not a
+    bounded quantity for ANY 8-bit forward.  Gated instead: (a) rel-L2 <= 1e-1 per tensor at the
+    INITIAL weights (`at_init`, same size, same inputs), where every tensor carries signal; (b) at the
+    trained state, the error of the Adam update the gradient causes, RMS per tensor of
+    (g_bf16 - g_exact) / (sqrt(vhat) + eps) <= 0.1 learning rates; the raw rel-L2 figures of the trained
+    state are reported next to it (`grad_tensors_over_bound`)."""
+    def live_rel(per):
+        gmax = max((t[1] for t in per), default=0.0)
+        return [(t[0], t[2] / t[1]) for t in per if t[1] > 1e-7 * gmax and t[1] > 0]
+
+    per = parity.pop("per_tensor")
+    accurate = mode in (0, 1, 3)
+    bound = GRAD_BOUND_FP32 if accurate else GRAD_BOUND_REDUCED
+    live = live_rel(per)
+    over = sorted(((n, r) for n, r in live if r > bound), key=lambda t: -t[1])
+    parity["grad_tensors_checked"] = len(live)
+    parity["grad_tensors_over_bound"] = [[n, float(f"{r:.3g}")] for n, r in over[:8]]
+    rs = sorted(r for _, r in live)
+    parity["grad_rel_l2_median"] = float(f"{rs[len(rs) // 2]:.3g}") if rs else None
+    for k in ("out_max_abs_vs_exact_fp32", "out_rel_l2_vs_exact_fp32", "worst_grad_rel_l2", "all_grads_rel_l2"):
+        parity[k] = float(f"{parity[k]:.4g}")
+    if accurate:      # fp32-accurate cores: the north_star's 1e-4 on the outputs
+        parity["gate"] = {"out_max_abs": 1e-4, "per_tensor_grad_rel_l2": bound}
+        parity["ok"] = bool(parity["out_max_abs_vs_exact_fp32"] <= 1e-4 and not over)
+        return parity
+    # reduced precision: SURVEY 8(d)'s 5e-2 on the outputs, read as a relative figure (it was taken from
+    # the reference under bf16 autocast: 1.7e-2 rel-L2 = 7.9e-2 max-abs in eval mode, 5.9e-2 / 4.0e-1 in
+    # train mode on the G2 inputs - tests/golden/g9_bf16_autocast.npz), and the gradient gates above
+    ok = parity["out_rel_l2_vs_exact_fp32"] <= 5e-2
+    gate = {"out_rel_l2": 5e-2, "reference_under_bf16_autocast": {"train_out_rel_l2": 5.9e-2, "train_out_max_abs": 0.397}}
+    upd = [(t[0], t[3]) for t in per if t[3] is not None]
+    if upd:
+        wn, wu = max(upd, key=lambda t: t[1])
+        parity["adam_update_err_rms_lr_worst"] = float(f"{wu:.3g}")
+        parity["adam_update_err_worst_tensor"] = wn
+        gate["adam_update_err_rms_lr"] = UPDATE_BOUND
+        ok = ok and wu <= UPDATE_BOUND
+    if at_init is not None:
+        li = live_rel(at_init.pop("per_tensor"))
+        oi = sorted(((n, r) for n, r in li if r > bound), key=lambda t: -t[1])
+        wi = max(li, key=lambda t: t[1]) if li else ("", 0.0)
+        parity["at_init"] = {"grad_tensors_checked": len(li), "worst_grad_rel_l2": float(f"{wi[1]:.3g}"), "worst_grad": wi[0],
+                             "grad_tensors_over_bound": [[n, float(f"{r:.3g}")] for n, r in oi[:8]],
+                             "out_rel_l2_vs_exact_fp32": float(f"{at_init['out_rel_l2_vs_exact_fp32']:.3g}"),
+                             "out_max_abs_vs_exact_fp32": float(f"{at_init['out_max_abs_vs_exact_fp32']:.3g}")}
+        gate["at_init_per_tensor_grad_rel_l2"] = bound
+        ok = ok and not oi
+    elif not upd:
+        gate["per_tensor_grad_rel_l2"] = bound
+        ok = ok and not over
+    parity["gate"] = gate
+    parity["ok"] = bool(ok)
+    return parity
+
+
+def _timed_steps(fn, warmup, steps, dev):
+    import torch
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def extra_workloads(dev, lib, headline_mode, budget_s=270.0):
+    """The other BASELINE.json configs under the same clock as the headline, run AFTER its timed
+    region and parity step (rank 0, N=1): config 3 (bf16 training step + per-tensor parity), config 5
+    (whole-scene refinement, fp16 forward), the encoder alone through the single fused kernel (the
+    north_star's fused shared MLP + max-pool; both precisions), config 4's per-rank share (B=512,
+    N=2048) and the reference's own per-GPU batch (B=32, N=2048; eager and HIP graph).  Each entry
+    carries its own wall time; an entry that fails or no longer fits the budget says so."""
+    import numpy as np
+    import torch
+    from pointnet_refine_amd import ops
+    from pointnet_refine_amd.model import LineRefineNet, MultiScalePointNetEncoder
+    from pointnet_refine_amd.synth import synthetic_batch
+    from pointnet_refine_amd.train_step import TrainStep
+    t_start = time.perf_counter()
+    out = {}
+
+    def clean():
+        ops.release_workspaces()
+        torch.cuda.empty_cache()
+
+    def guarded(name, fn):
+        if time.perf_counter() - t_start > budget_s:
+            out[name] = {"skipped": f"budget of {budget_s:.0f} s used up"}
+            return
+        t0 = time.perf_counter()
+        try:
+            out[name] = fn()
+        except Exception as e:      # report, never hide
+            out[name] = {"error": f"{type(e).__name__}: {str(e)[:160]}"}
+        finally:
+            lib.prh_set_gemm_mode(headline_mode)
+            clean()
+        out[name]["wall_s"] = round(time.perf_counter() - t0, 2)
+        log(f"workload {name}: {out[name]}")
+
+    def train_wl(B, N, mode, steps, warmup, graph=False, parity=False, chunk=2048):
+        lib.prh_set_gemm_mode(mode)
+        torch.manual_seed(0)
+        model = LineRefineNet().to(dev).train()
+        step = TrainStep(model, None, decoder_chunk=chunk, graph=graph)
+        batch = synthetic_batch(B, N, dev, seed=1234)
+        p_init = parity_check(step, model, batch, lib, mode, dev) if (parity and mode in (2, 4)) else None
+        torch.cuda.reset_peak_memory_stats(dev)
+        ms = _timed_steps(lambda: step(*batch), warmup, steps, dev)
+        r = {"workload": f"LineRefineNet training step, B={B}, N={N}" + (", HIP graph" if graph else ""),
+             "dtype": MODE_INFO[mode][3], "ms_per_step": round(ms, 3), "segments_per_s": round(B / ms * 1e3, 1),
+             "steps": steps, "warmup": warmup, "max_mem_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1)}
+        if parity:
+            vhat = step.opt.exp_avg_sq / (1.0 - step.opt.param_groups[0]["betas"][1] ** step.opt.steps)
+            r["parity"] = grade_parity(parity_check(step, model, batch, lib, mode, dev, vhat=vhat if mode in (2, 4) else None),
+                                       mode, p_init)
+        step.close()
+        return r
+
+    guarded("config3_bf16_train_step", lambda: train_wl(4096, 1024, 4, steps=6, warmup=2, parity=True))
+    guarded("config4_per_rank_share_B512_N2048", lambda: train_wl(512, 2048, 3, steps=6, warmup=2))
+    guarded("reference_batch_B32_N2048_eager", lambda: train_wl(32, 2048, 3, steps=30, warmup=5, chunk=None))
+    guarded("reference_batch_B32_N2048_graph", lambda: train_wl(32, 2048, 3, steps=30, warmup=5, graph=True, chunk=None))
+
+    def encoder_eval(prec):
+        torch.manual_seed(0)
+        enc = MultiScalePointNetEncoder(4, 1024).to(dev).eval()
+        enc.inference_precision = prec
+        B, N = 4096, 1024
+        ctx, _, _ = synthetic_batch(B, N, dev, seed=1234)
+        with torch.no_grad():
+            ms = _timed_steps(lambda: enc.forward_pointmajor(ctx, True), 2, 5, dev)
+        flops = 5_587_584.0 * N * B
+        products = 1 if prec == "fp16" else 3
+        peak = BF16_MFMA_PEAK_TFLOPS / products
+        byts = (16.0 * N + 4096.0 * N + 8192.0) * B
+        return {"workload": "MultiScalePointNetEncoder eval forward -> (global_feat, fused), ONE fused kernel, B=4096, N=1024",
+                "dtype": "fp16 operands, fp32 accumulate" if prec == "fp16" else "f32 (2xfp16-split MFMA, 3 products)",
+                "ms": round(ms, 3), "segments_per_s": round(B / ms * 1e3, 1),
+                "mfma": {"achieved_tflops": round(flops / ms / 1e9, 1), "peak": round(peak, 1),
+                         "frac": round(flops / ms / 1e9 / peak, 4)},
+                "hbm": {"algorithmic_gbs": round(byts / ms / 1e6, 1), "frac_of_8TBs": round(byts / ms / 1e6 / HBM_PEAK_GBS, 4)}}
+
+    guarded("encoder_eval_fused_fp16", lambda: encoder_eval("fp16"))
+    guarded("encoder_eval_fused_fp32_accurate", lambda: encoder_eval("fp32"))
+
+    def scene():
+        from pointnet_refine_amd.io import refine_scene
+        P, L = 100_000, 4096
+        rng = np.random.default_rng(0)
+        lines = []
+        for _ in range(L):
+            x = np.sort(rng.uniform(-60, 60, 6))
+            lines.append(np.stack([x, rng.uniform(-40, 40) + 0.2 * np.sin(x / 9), rng.normal(0, 0.02, 6)], 1))
+        xyz = np.stack([rng.uniform(-60, 60, P), rng.uniform(-40, 40, P), rng.normal(0, 0.05, P)], 1)
+        cloud = torch.from_numpy(np.column_stack([xyz, np.clip(rng.exponential(12, P), 0, 255)]).astype(np.float32)).to(dev)
+        torch.manual_seed(0)
+        model = LineRefineNet().to(dev).eval()
+        res = {}
+        for prec in ("layers", "fp32", "fp16"):
+            refine_scene(model, cloud, lines[:2048], precision=prec)
+            torch.cuda.synchronize(dev)
+            best = 1e9
+            for _ in range(2):
+                t0 = time.perf_counter()
+                refined, _ = refine_scene(model, cloud, lines, seed=1, precision=prec)
+                torch.cuda.synchronize(dev)
+                best = min(best, time.perf_counter() - t0)
+            res[prec] = (best, refined)
+        ref = res["layers"][1]
+        return {"workload": "io.refine_scene: 100k-point cloud, 4096 polylines -> 4096 x (1024, 4) contexts on the GPU, "
+                            "eval forward in batches of 2048, end to end incl. copy back",
+                "fp16_lines_per_s": round(L / res["fp16"][0], 1), "fp16_ms": round(res["fp16"][0] * 1e3, 1),
+                "fp16_max_abs_vs_per_layer_fp32": float(f"{float(np.abs(res['fp16'][1] - ref).max()):.3g}"),
+                "fp32_accurate_lines_per_s": round(L / res["fp32"][0], 1),
+                "fp32_accurate_max_abs_vs_per_layer_fp32": float(f"{float(np.abs(res['fp32'][1] - ref).max()):.3g}"),
+                "per_layer_fp32_lines_per_s": round(L / res["layers"][0], 1)}
+
+    guarded("config5_whole_scene", scene)
+    out["total_wall_s"] = round(time.perf_counter() - t_start, 1)
+    return out
 
 
 def run(args):
@@ -371,6 +584,13 @@ def run(args):
     def mem_gib():
         return 0.0 if args.stub else torch.cuda.max_memory_allocated(dev) / 2**30
 
+    parity_init = None
+    if lib is not None and mode in (2, 4) and not args.no_parity and not args.graph:
+        # reduced precision: per-tensor gradient parity at the INITIAL weights (see grade_parity)
+        try:
+            parity_init = parity_check(step, model, (ctx, noisy, target), lib, mode, dev)
+        except torch.cuda.OutOfMemoryError:
+            parity_init = None
     for i in range(args.warmup):
         loss = step(ctx, noisy, target)
         if rank == 0:
@@ -475,20 +695,10 @@ def run(args):
     parity = None
     if lib is not None and not args.no_parity and not args.graph:
         try:
-            parity = parity_check(step, model, (ctx, noisy, target), lib, mode, dev)
-            if mode in (0, 1, 3):      # fp32-accurate cores: the north_star's 1e-4 on the outputs
-                gate = {"out_max_abs": 1e-4, "worst_grad_rel_l2": 2e-3}
-                parity["ok"] = bool(parity["out_max_abs_vs_exact_fp32"] <= 1e-4 and parity["worst_grad_rel_l2"] <= 2e-3)
-            else:
-                # reduced precision: SURVEY 8(d)'s 5e-2, read as a relative figure (it was taken from
-                # the reference under bf16 autocast: 1.7e-2 rel-L2 = 7.9e-2 max-abs in eval mode, and
-                # 5.9e-2 / 4.0e-1 in train mode on the G2 inputs - tests/golden/g9_bf16_autocast.npz)
-                gate = {"out_rel_l2": 5e-2, "reference_under_bf16_autocast": {"train_out_rel_l2": 5.9e-2,
-                                                                              "train_out_max_abs": 0.397}}
-                parity["ok"] = bool(parity["out_rel_l2_vs_exact_fp32"] <= 5e-2)
-            parity["gate"] = gate
-            for k in ("out_max_abs_vs_exact_fp32", "out_rel_l2_vs_exact_fp32", "worst_grad_rel_l2", "all_grads_rel_l2"):
-                parity[k] = float(f"{parity[k]:.4g}")
+            vhat = None
+            if mode in (2, 4) and getattr(step.opt, "exp_avg_sq", None) is not None and step.opt.steps > 0:
+                vhat = step.opt.exp_avg_sq / (1.0 - step.opt.param_groups[0]["betas"][1] ** step.opt.steps)
+            parity = grade_parity(parity_check(step, model, (ctx, noisy, target), lib, mode, dev, vhat=vhat), mode, parity_init)
             if rank == 0:
                 log(f"parity at B={B}, N={N}: {parity}")
         except torch.cuda.OutOfMemoryError as e:       # report, never hide
@@ -498,6 +708,22 @@ def run(args):
         f = torch.tensor([1.0 if parity_failed else 0.0], device=dev)
         dist.all_reduce(f, op=dist.ReduceOp.MAX)
         parity_failed = bool(f.item() > 0)
+
+    workloads = None
+    if (rank == 0 and world == 1 and lib is not None and not args.no_workloads and not args.graph
+            and B == 4096 and N == 1024):
+        # free the headline run's buffers first: config 3 alone needs ~140 GB
+        final_loss = float(loss)
+        from pointnet_refine_amd import ops as _ops
+        step.close()
+        del step, model, opt
+        ctx = noisy = target = None
+        _ops.release_workspaces()
+        torch.cuda.empty_cache()
+        hl_mem = mem_gib()
+        workloads = extra_workloads(dev, lib, mode)
+    else:
+        final_loss, hl_mem = float(loss), mem_gib()
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -516,13 +742,15 @@ def run(args):
                        "global_batch": world * B, "points": N,
                        "parallelism": f"dp{world}" + (f" ({backend})" if world > 1 else ""),
                        "decoder_chunk": args.decoder_chunk},
-            "loss": round(float(loss), 6),
-            "max_mem_gb": round(mem_gib(), 1),
+            "loss": round(final_loss, 6),
+            "max_mem_gb": round(hl_mem, 1),
         }
         if roofline is not None:
             line["roofline"] = roofline
         if parity is not None:
             line["parity"] = parity
+        if workloads is not None:
+            line["workloads"] = workloads
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, args.cpu_batch)
         emit(line)

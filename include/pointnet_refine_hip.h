@@ -203,13 +203,16 @@ int prh_attn_backward_kv16(const float* q, long ldq, const uint16_t* k, long ldk
  *            (prh_encoder_fused_image_bytes bytes, 256-byte aligned); proj_w/proj_b [256,1024]/[256]
  *            or NULL (encoder API only);
  *   forward: any of memory / fused / gfeat may be NULL (at least one given); workspace
- *            (prh_encoder_fused_workspace_bytes) is needed for gfeat only. */
+ *            (prh_encoder_fused_workspace_bytes) is needed for gfeat only.  Activations travel between
+ *            the layers as fp16 planes: `saturated` (device word, may be NULL) is INCREMENTED for every
+ *            group of four activations holding a value above 65504 (clamped) - a non-zero count means
+ *            the result is not the module's and must be discarded (the caller zeroes the word). */
 size_t prh_encoder_fused_image_bytes(int planes, int in_channel);
 int prh_encoder_fused_prepare(const prh_encoder_params* prm, float eps, const float* proj_w, const float* proj_b,
                               int planes, void* image, size_t image_bytes, int device, void* stream);
 size_t prh_encoder_fused_workspace_bytes(int B, int N, int planes);
 int prh_encoder_fused_forward(const void* image, int planes, int in_channel, int has_proj, const float* ctx, int B,
-                              int N, float* memory, float* fused, float* gfeat, void* workspace,
+                              int N, float* memory, float* fused, float* gfeat, unsigned* saturated, void* workspace,
                               size_t workspace_bytes, int device, void* stream);
 
 /* nn.Linear forward y = act(x W^T + b): context_proj (src/model.py:147,194) and any

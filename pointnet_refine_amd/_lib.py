@@ -17,8 +17,9 @@ _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("PRH_LIB_PATH") or os.path.join(_HERE, "libpointnet_refine_hip.so")
 _CSRC = os.path.join(_HERE, "csrc")
 # every file of csrc/ counts for staleness (prh_lib.hip is the one translation unit; it includes the rest)
-_SOURCES = [os.path.join(_CSRC, "prh_lib.hip")] + sorted(
+_SOURCES = [os.path.join(_CSRC, "prh_lib.hip")] + (sorted(
     os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hpp", ".h", ".hip")) and f != "prh_lib.hip")
+    if os.path.isdir(_CSRC) else [])      # a binary-only install has no csrc/: nothing can be stale
 _HEADER = os.path.join(_ROOT, "include", "pointnet_refine_hip.h")
 
 PRH_MAX_LAYERS = 8
@@ -150,7 +151,7 @@ def _bind(lib):
     lib.prh_encoder_fused_workspace_bytes.restype = sz
     lib.prh_encoder_fused_workspace_bytes.argtypes = [i, i, i]
     lib.prh_encoder_fused_forward.restype = i
-    lib.prh_encoder_fused_forward.argtypes = [vp, i, i, i, vp, i, i, vp, vp, vp, vp, sz, i, vp]
+    lib.prh_encoder_fused_forward.argtypes = [vp, i, i, i, vp, i, i, vp, vp, vp, vp, vp, sz, i, vp]
     lib.prh_linear_forward.restype = i
     lib.prh_linear_forward.argtypes = [vp, lg, vp, vp, vp, i, i, i, i, vp, sz, i, vp]
     lib.prh_linear_forward_ex.restype = i

@@ -69,6 +69,117 @@ __global__ __launch_bounds__(256) void cast_b16_kernel(const float* __restrict__
   *reinterpret_cast<unsigned*>(dst + r * ldd + c) = pack_bf16x2(a, b);
 }
 
+// ---------------------------------------------------------------------------------------
+// First layer of the bf16 mode on fp32 OPERANDS (src/model.py:10,15,43: conv1 + bn1): the
+// context rows (x, y, z in metres, raw intensity) are never cast to bf16.  K = in_channel <= 8 is
+// VALU work, not a GEMM: one workgroup = one 128-row statistics tile, a thread = one row x CO/2
+// output channels, z = b + W x in fp32 (fmaf chain in channel order), ROUNDED to bf16 as stored,
+// and the tile's per-column sum / centred M2 taken of the rounded values (the tensor the next
+// kernels read back), in the ws_a / ws_b [tile][CO] format of the GEMM statistics epilogue.
+// ---------------------------------------------------------------------------------------
+template <int CO>
+__global__ __launch_bounds__(256) void conv_in_b16_kernel(const float* __restrict__ x, int C, const float* __restrict__ W,
+                                                          const float* __restrict__ b, unsigned short* __restrict__ z,
+                                                          long ldz, int P, int want_stats, float* __restrict__ ws_a,
+                                                          float* __restrict__ ws_b) {
+  static_assert(CO % 16 == 0 && CO <= 128, "conv_in_b16: output width");
+  constexpr int HC = CO / 2;
+  __shared__ float sw[CO * 8 + CO];
+  __shared__ float sv[128][CO + 1];
+  __shared__ float red[4][CO];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < CO * 8; i += 256) {
+    const int co = i >> 3, c = i & 7;
+    sw[i] = c < C ? W[(size_t)co * C + c] : 0.f;
+  }
+  for (int i = tid; i < CO; i += 256) sw[CO * 8 + i] = b != nullptr ? b[i] : 0.f;
+  __syncthreads();
+  const int lr = tid >> 1, half = tid & 1;
+  const long row = (long)blockIdx.x * 128 + lr;
+  const bool rok = row < P;
+  float xv[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) xv[c] = (rok && c < C) ? x[(size_t)row * C + c] : 0.f;
+  float out[HC];
+#pragma unroll
+  for (int j = 0; j < HC; ++j) {
+    const int co = half * HC + j;
+    float a = sw[CO * 8 + co];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) a = fmaf(sw[co * 8 + c], xv[c], a);
+    out[j] = bf16_round(a);
+  }
+  if (rok) {
+    unsigned short* q = z + (size_t)row * ldz + half * HC;
+#pragma unroll
+    for (int j = 0; j < HC; j += 8)
+      *reinterpret_cast<uint4*>(q + j) = make_uint4(pack_bf16x2(out[j], out[j + 1]), pack_bf16x2(out[j + 2], out[j + 3]),
+                                                    pack_bf16x2(out[j + 4], out[j + 5]), pack_bf16x2(out[j + 6], out[j + 7]));
+  }
+  if (!want_stats) return;
+#pragma unroll
+  for (int j = 0; j < HC; ++j) sv[lr][half * HC + j] = out[j];
+  __syncthreads();
+  int nrows = P - (int)((long)blockIdx.x * 128);
+  nrows = nrows > 128 ? 128 : nrows;
+  // 256 threads = CO columns x (256 / CO) row groups
+  constexpr int G = 256 / CO, RG = 128 / G;
+  const int col = tid % CO, g = tid / CO;
+  float s = 0.f;
+  for (int r = g * RG; r < (g + 1) * RG; ++r)
+    if (r < nrows) s += sv[r][col];
+  red[g][col] = s;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int k = 0; k < G; ++k) tot += red[k][col];
+  const float mean = tot / (float)nrows;
+  float m2 = 0.f;
+  for (int r = g * RG; r < (g + 1) * RG; ++r)
+    if (r < nrows) { const float d = sv[r][col] - mean; m2 = fmaf(d, d, m2); }
+  __syncthreads();
+  red[g][col] = m2;
+  __syncthreads();
+  if (g == 0) {
+    float m2t = 0.f;
+#pragma unroll
+    for (int k = 0; k < G; ++k) m2t += red[k][col];
+    ws_a[(size_t)blockIdx.x * CO + col] = tot;
+    ws_b[(size_t)blockIdx.x * CO + col] = m2t;
+  }
+}
+
+// Its weight gradient, dW[co][c] = sum_p dz[p][co] x[p][c], with the fp32 context rows as the second
+// operand: a thread = one output channel x one of four row lanes, C <= 8 running sums in fp32,
+// per-workgroup partials [block][CO][C] summed in fp64 by slab_reduce_kernel.
+template <int CO>
+__global__ __launch_bounds__(256) void conv_in_wgrad_b16_kernel(const unsigned short* __restrict__ dz, long lddz,
+                                                                const float* __restrict__ x, int C, int P,
+                                                                int rows_per_block, float* __restrict__ part) {
+  static_assert(CO == 64, "conv_in_wgrad_b16: one wave per row lane");
+  __shared__ float red[4][CO][8];
+  const int tid = threadIdx.x, co = tid & 63;
+  const int rg = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  long r1 = r0 + rows_per_block;
+  r1 = r1 > P ? P : r1;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (long r = r0 + rg; r < r1; r += 4) {
+    const float d = __uint_as_float((unsigned)dz[(size_t)r * lddz + co] << 16);
+    const float* xr = x + (size_t)r * C;       // wave-uniform row: broadcast loads
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (c < C) acc[c] = fmaf(d, xr[c], acc[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c) red[rg][co][c] = acc[c];
+  __syncthreads();
+  for (int i = tid; i < CO * C; i += 256) {
+    const int o = i / C, c = i - o * C;
+    part[(size_t)blockIdx.x * CO * C + i] = red[0][o][c] + red[1][o][c] + red[2][o][c] + red[3][o][c];
+  }
+}
+
 __device__ __forceinline__ void unpack8(const uint4 u, float (&f)[8]) {
   f[0] = bf16_lo(u.x); f[1] = bf16_hi(u.x); f[2] = bf16_lo(u.y); f[3] = bf16_hi(u.y);
   f[4] = bf16_lo(u.z); f[5] = bf16_hi(u.z); f[6] = bf16_lo(u.w); f[7] = bf16_hi(u.w);

@@ -121,6 +121,7 @@ struct FusedParams {
   float* memory;              // [B, N, 256] or null (no context_proj)
   float* fused;               // [B, N, 1024] or null
   float* pool_ws;             // [B * tiles_per_seg][2][1024] partial max / sum, or null
+  unsigned* sat;              // device counter of activation groups that exceeded the fp16 range, or null
 };
 
 template <int NPL> struct FE {
@@ -135,9 +136,15 @@ __device__ __forceinline__ uint2 fe_pack4(float a, float b, float c, float d) {
   f16x2 h0 = __builtin_convertvector(v0, f16x2), h1 = __builtin_convertvector(v1, f16x2);
   return make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
 }
-// 4 values -> fp16 plane(s) at `p` (8 B per plane, planes PL apart); values clamped to the fp16 range
+// 4 values -> fp16 plane(s) at `p` (8 B per plane, planes PL apart); values clamped to the fp16 range.
+// Post-BatchNorm activations are O(1) for a trained checkpoint, but that is a property of the weights,
+// not of the module: every value passes through the thread's running maximum `vmax` (two v_max3 per
+// group, no branch), the kernel's last act is one atomic on *sat if that maximum exceeded 65504, and
+// the host side refuses the result (ops.encoder_eval_fused -> per-layer kernels / RuntimeError).
 template <int NPL>
-__device__ __forceinline__ void fe_put4(char* p, float a, float b, float c, float d) {
+__device__ __forceinline__ void fe_put4(char* p, float a, float b, float c, float d, float& vmax) {
+  vmax = fmaxf(fmaxf(vmax, a), b);
+  vmax = fmaxf(fmaxf(vmax, c), d);
   a = fminf(a, 65504.f); b = fminf(b, 65504.f); c = fminf(c, 65504.f); d = fminf(d, 65504.f);
   if (NPL == 1) {
     *reinterpret_cast<uint2*>(p) = fe_pack4(a, b, c, d);
@@ -219,7 +226,7 @@ __device__ __forceinline__ void fe_gemm(f32x4 (&acc)[R][FE<NPL>::CB], const char
 // kb_base + (n >> 5), row = point, column n & 31.  ch0: the wave's first channel.
 template <int NPL, int R, bool RELU>
 __device__ __forceinline__ void fe_store_act(const f32x4 (&acc)[R][FE<NPL>::CB], char* lds, int kb_base, int ch0,
-                                             const float* bias, float invs, int l15, int q) {
+                                             const float* bias, float invs, int l15, int q, float& vmax) {
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int n = ch0 + r * 16 + 4 * q;
@@ -229,7 +236,7 @@ __device__ __forceinline__ void fe_store_act(const f32x4 (&acc)[R][FE<NPL>::CB],
       float v0 = fmaf(acc[r][c][0], invs, b.x), v1 = fmaf(acc[r][c][1], invs, b.y);
       float v2 = fmaf(acc[r][c][2], invs, b.z), v3 = fmaf(acc[r][c][3], invs, b.w);
       if (RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-      fe_put4<NPL>(lds + (size_t)(kb_base + (n >> 5)) * FE<NPL>::KB + h2_off(c * 16 + l15, n & 31), v0, v1, v2, v3);
+      fe_put4<NPL>(lds + (size_t)(kb_base + (n >> 5)) * FE<NPL>::KB + h2_off(c * 16 + l15, n & 31), v0, v1, v2, v3, vmax);
     }
   }
 }
@@ -257,6 +264,7 @@ __global__ __launch_bounds__(512, 2) void encoder_fused_kernel(const FusedParams
   const size_t row0 = (size_t)seg * p.N + n0;
   const int C = p.L.C;
   const char* img = p.img;
+  float vmax = 0.f;                 // largest activation this thread put into an fp16 plane
   const float* invs = reinterpret_cast<const float*>(img + p.L.invs);
   auto wptr = [&](int layer, int R) {     // this wave's first fragment of a layer
     return img + p.L.w[layer] + (size_t)(wave * R) * (FE_K[layer] / 32) * NPL * 1024 + lane * 16;
@@ -288,8 +296,8 @@ __global__ __launch_bounds__(512, 2) void encoder_fused_kernel(const FusedParams
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = fmaxf(o[j], 0.f);
       char* d = smem + (size_t)(KB_H1 + (g >> 2)) * T::KB + h2_off(pt, (g & 3) * 8);
-      fe_put4<NPL>(d, o[0], o[1], o[2], o[3]);
-      fe_put4<NPL>(d + 8, o[4], o[5], o[6], o[7]);
+      fe_put4<NPL>(d, o[0], o[1], o[2], o[3], vmax);
+      fe_put4<NPL>(d + 8, o[4], o[5], o[6], o[7], vmax);
     }
   }
   __syncthreads();
@@ -298,14 +306,14 @@ __global__ __launch_bounds__(512, 2) void encoder_fused_kernel(const FusedParams
   {
     f32x4 a2[1][CB]; fe_zero(a2);
     fe_gemm<NPL, 1>(a2, smem, KB_H1, 2, wptr(0, 1), rbs(0), l15, q, f2);
-    fe_store_act<NPL, 1, true>(a2, smem, KB_H2, wave * 16, biasp(0), invs[0], l15, q);
+    fe_store_act<NPL, 1, true>(a2, smem, KB_H2, wave * 16, biasp(0), invs[0], l15, q, vmax);
   }
   __syncthreads();
   FeW<NPL, 4> f4 = fe_first<NPL, 4>(wptr(2, 4), rbs(2));
   {
     f32x4 a3[2][CB]; fe_zero(a3);
     fe_gemm<NPL, 2>(a3, smem, KB_H2, 4, wptr(1, 2), rbs(1), l15, q, f3);
-    fe_store_act<NPL, 2, true>(a3, smem, KB_H3, wave * 32, biasp(1), invs[1], l15, q);
+    fe_store_act<NPL, 2, true>(a3, smem, KB_H3, wave * 32, biasp(1), invs[1], l15, q, vmax);
   }
   __syncthreads();
   const char* wfus = wptr(4, 8);
@@ -313,7 +321,7 @@ __global__ __launch_bounds__(512, 2) void encoder_fused_kernel(const FusedParams
   {
     f32x4 a4[4][CB]; fe_zero(a4);
     fe_gemm<NPL, 4>(a4, smem, KB_H3, 8, wptr(2, 4), rbs(2), l15, q, f4);
-    fe_store_act<NPL, 4, true>(a4, smem, KB_H4, wave * 64, biasp(2), invs[2], l15, q);
+    fe_store_act<NPL, 4, true>(a4, smem, KB_H4, wave * 64, biasp(2), invs[2], l15, q, vmax);
   }
   __syncthreads();
   // ---- fusion conv, K range of h1..h4 (960 channels = k-blocks 0..29, in concat order)
@@ -347,7 +355,7 @@ __global__ __launch_bounds__(512, 2) void encoder_fused_kernel(const FusedParams
     FeW<NPL, 4> fa = fe_first<NPL, 4>(wf4, rbs(4));
     fe_gemm<NPL, 2>(a5, smem, KB_H4, 16, w5, rbs(3), l15v, qv, f5);
     if (ch > 0) __syncthreads();                // the previous chunk's fusion reads are done
-    fe_store_act<NPL, 2, true>(a5, smem, KB_H5, wave * 32, biasp(3) + ch * 256, invs[3], l15v, qv);
+    fe_store_act<NPL, 2, true>(a5, smem, KB_H5, wave * 32, biasp(3) + ch * 256, invs[3], l15v, qv, vmax);
     __syncthreads();
     FeW<NPL, 4> fb = fe_first<NPL, 4>(wf4 + 4 * rbs(4), rbs(4));
     fe_gemm<NPL, 4>(F[0], smem, KB_H5, 8, wf4, rbs(4), l15v, qv, fa);
@@ -367,8 +375,8 @@ __global__ __launch_bounds__(512, 2) void encoder_fused_kernel(const FusedParams
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = fmaxf(fmaf(iv, gw[g * 8 + j], gb[g * 8 + j]), 0.f);
       char* d = smem + (size_t)(g >> 2) * T::KB + h2_off(pt, (g & 3) * 8);
-      fe_put4<NPL>(d, o[0], o[1], o[2], o[3]);
-      fe_put4<NPL>(d + 8, o[4], o[5], o[6], o[7]);
+      fe_put4<NPL>(d, o[0], o[1], o[2], o[3], vmax);
+      fe_put4<NPL>(d + 8, o[4], o[5], o[6], o[7], vmax);
     }
   }
   __syncthreads();
@@ -420,11 +428,14 @@ __global__ __launch_bounds__(512, 2) void encoder_fused_kernel(const FusedParams
       }
     }
   }
-  if (p.memory == nullptr) return;
+  if (p.memory == nullptr) {
+    if (p.sat != nullptr && !(vmax <= 65504.f)) atomicAdd(p.sat, 1u);
+    return;
+  }
   __syncthreads();                               // u is dead
   // ---- context_proj: F -> fp16 planes (k-blocks 0..31), memory = W_p F + b_p
-  fe_store_act<NPL, 4, false>(F[0], smem, 0, wave * 128, nullptr, 1.f, l15, q);
-  fe_store_act<NPL, 4, false>(F[1], smem, 0, wave * 128 + 64, nullptr, 1.f, l15, q);
+  fe_store_act<NPL, 4, false>(F[0], smem, 0, wave * 128, nullptr, 1.f, l15, q, vmax);
+  fe_store_act<NPL, 4, false>(F[1], smem, 0, wave * 128 + 64, nullptr, 1.f, l15, q, vmax);
   __syncthreads();
   {
     f32x4 am[2][CB]; fe_zero(am);
@@ -443,6 +454,7 @@ __global__ __launch_bounds__(512, 2) void encoder_fused_kernel(const FusedParams
                           fmaf(am[r][c][3], sp, b4.w));
     }
   }
+  if (p.sat != nullptr && !(vmax <= 65504.f)) atomicAdd(p.sat, 1u);
 }
 
 // global_feat = [max over the segment's tiles | sum / N]

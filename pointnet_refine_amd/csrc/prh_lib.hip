@@ -117,18 +117,28 @@ inline int gemm_mode() {
   if (g_gemm_mode < 0) {
     const char* e = getenv("PRH_GEMM");
     g_gemm_mode = PRH_GEMM_DEFAULT;
+    // one spelling table for PRH_GEMM, ops.set_gemm_mode() and bench.py --gemm (ops.GEMM_MODES):
+    // fp32 0, split 1, bf16op 2, split16 3, bf16 4 ("bf16s": round-2 alias of mode 4)
     if (e != nullptr && strcmp(e, "fp32") == 0) g_gemm_mode = 0;
     else if (e != nullptr && strcmp(e, "split") == 0) g_gemm_mode = 1;
-    else if (e != nullptr && strcmp(e, "bf16") == 0) g_gemm_mode = 2;
+    else if (e != nullptr && strcmp(e, "bf16op") == 0) g_gemm_mode = 2;
     else if (e != nullptr && strcmp(e, "split16") == 0) g_gemm_mode = 3;
-    else if (e != nullptr && strcmp(e, "bf16s") == 0) g_gemm_mode = 4;
+    else if (e != nullptr && (strcmp(e, "bf16") == 0 || strcmp(e, "bf16s") == 0)) g_gemm_mode = 4;
   }
   return g_gemm_mode;
 }
 // Mode 4 (bf16 operands AND bf16 activation storage, prh_b16.hpp) has its own encoder / Linear
 // entry points; whatever still goes through the generic fp32-storage launchers in that mode
 // (point_mlp stack, odd shapes) is served like mode 2: one bf16 plane on the first-generation cores.
-inline int core_mode() { return gemm_mode() == 4 ? 2 : gemm_mode(); }
+// (the point_mlp stack - 3-wide line coordinates in metres, B*32 rows - is the exception: in mode 4 it
+// runs on the fp32-accurate split-fp16 cores, see CoreOverride)
+thread_local int t_core_override = -1;
+inline int core_mode() { return t_core_override >= 0 ? t_core_override : (gemm_mode() == 4 ? 2 : gemm_mode()); }
+struct CoreOverride {
+  int old;
+  explicit CoreOverride(int m) : old(t_core_override) { t_core_override = m; }
+  ~CoreOverride() { t_core_override = old; }
+};
 // PRH_H2_GEN=1 keeps the split-fp16 NT GEMMs on the first-generation core (32x32x16 MFMA, BK 16)
 bool g_h2_gen2 = [] { const char* e = getenv("PRH_H2_GEN"); return !(e && strcmp(e, "1") == 0); }();
 // PRH_TN_TR=0 keeps the split-fp16 wgrads on the column-staged core
@@ -198,7 +208,7 @@ int materialize_dz(float* dy, long lddy, const float* z, long ldz, const float* 
 }
 // dz is materialised when the layer is aligned for 16-B accesses and the split-fp16 cores are on
 inline bool dz_in_place(int cols, long lddy, long ldz) {
-  return gemm_mode() == 3 && (cols & 3) == 0 && (lddy & 3) == 0 && (ldz & 3) == 0;
+  return core_mode() == 3 && (cols & 3) == 0 && (lddy & 3) == 0 && (ldz & 3) == 0;
 }
 
 // Statistics partials: `count` tiles of `rows` rows each
@@ -390,7 +400,7 @@ int launch_nt(NTParams& p, hipStream_t st, StatInfo* si = nullptr) {   // p.amax
     return fail(PRH_ERR_ARG, "gemm_nt: K/lda/ldw must be multiples of 4 (K=%d lda=%ld ldw=%ld)",
                 p.K, p.lda, p.ldw);
   if constexpr (PRO == PRO_NONE && EPI == EPI_BIAS) {
-    if (gemm_mode() == 4 && nt_b16_generic_ok(p)) return launch_nt_b16<PRO_NONE, EPI_BIAS, false, false>(p, st, si);
+    if (gemm_mode() == 4 && t_core_override < 0 && nt_b16_generic_ok(p)) return launch_nt_b16<PRO_NONE, EPI_BIAS, false, false>(p, st, si);
   }
   // F_POOL is honoured by the vector epilogue only: cleared here, set again by the branch that
   // launches a kernel with that epilogue, so the caller can tell whether the partials exist
@@ -991,7 +1001,10 @@ typedef unsigned short u16;
 struct Enc16WS {
   u16* xpad; float* w0pad; float* ws_a; float* ws_b; float* ws_c; double* stat2; char* wprep;
   float *ca, *cb, *cc, *wT, *slab, *cslab, *dU, *gsum_a, *gsum_b; u16 *dy_cat, *dyf;
+  float* c1part;      // conv1 weight-gradient partials [C1_WGRAD_BLOCKS][cout][cin]
 };
+constexpr int C1_WGRAD_BLOCKS = 1024;
+inline bool conv_in_fp32_ok(int cin, int cout) { return cin <= 8 && cout == 64; }
 inline int cin_pad8(int c) { return (c + 7) / 8 * 8; }
 void enc16_carve(Arena& a, Enc16WS& e, int P, const int* ch /*[6]: cin, 64..od*/, int cat, int od, bool backward) {
   const int c0p = cin_pad8(ch[0]);
@@ -1028,6 +1041,7 @@ void enc16_carve(Arena& a, Enc16WS& e, int P, const int* ch /*[6]: cin, 64..od*/
   e.dyf = (u16*)a.f(((size_t)P * od + 1) / 2);
   e.dU = a.f((size_t)P * 64);
   e.gsum_a = a.f(64); e.gsum_b = a.f(64);
+  e.c1part = a.f((size_t)C1_WGRAD_BLOCKS * ch[1] * 8);
 }
 int cast_b16(const float* src, long lds_, int cs, u16* dst, long ldd, int cd, size_t rows, hipStream_t st) {
   const size_t n = rows * (size_t)(cd / 2);
@@ -1346,6 +1360,9 @@ int prh_mlp_stack_forward(const prh_bn_layer* layers, int n_layers, int relu_las
                           float* bn_mean, float* bn_rstd, void* workspace,
                           size_t workspace_bytes, int device, void* stream) {
   TRY(check_stack(layers, n_layers));
+  // bf16 mode: the line encoder (Conv1d(3,64) on coordinates of +-25 m, src/model.py:150-152) keeps
+  // fp32-accurate operands - 131 k rows at B=4096, nothing to gain from 8-bit mantissas
+  CoreOverride co_(gemm_mode() == 4 ? 3 : -1);
   if (!x || !z_cat || !y || !bn_scale || !bn_shift || !bn_mean || !bn_rstd || P <= 0)
     return fail(PRH_ERR_ARG, "mlp_stack_forward: bad argument");
   if (training && P < 2) return fail(PRH_ERR_ARG, "Expected more than 1 value per channel when training");
@@ -1375,6 +1392,7 @@ int prh_mlp_stack_backward(const prh_bn_layer* layers, int n_layers, int relu_la
                            const prh_bn_layer_grad* grads, float* dx, void* workspace,
                            size_t workspace_bytes, int device, void* stream) {
   TRY(check_stack(layers, n_layers));
+  CoreOverride co_(gemm_mode() == 4 ? 3 : -1);
   if (!x || !dy || !z_cat || P <= 0) return fail(PRH_ERR_ARG, "mlp_stack_backward: bad argument");
   HIP_TRY(hipSetDevice(device));
   hipStream_t st = (hipStream_t)stream;
@@ -1662,16 +1680,25 @@ int prh_encoder_forward_bf16(const prh_encoder_params* prm, const float* ctx, in
   if (!a.ok) return fail(PRH_ERR_WORKSPACE, "encoder_forward_bf16: workspace too small (%zu bytes)", workspace_bytes);
   StackDims d = stack_dims(prm->conv, 5);
   u16* z_cat = sv->z_cat;
-  // context rows -> bf16, padded to a multiple of 8 channels; conv1's weight padded alike
-  TRY(cast_b16(ctx, C, C, w.xpad, c0p, c0p, (size_t)P, st));
-  TRY(copy_cols(prm->conv[0].w, C, C, w.w0pad, c0p, c0p, (size_t)prm->conv[0].cout, st));
+  // conv1 on fp32 operands (VALU, K = in_channel): x, y, z in metres and the raw intensity are never
+  // rounded to bf16.  Other first-layer shapes: context rows -> bf16 padded to 8 channels, bf16 core
+  const bool c1_fp32 = conv_in_fp32_ok(C, prm->conv[0].cout);
+  if (!c1_fp32) {
+    TRY(cast_b16(ctx, C, C, w.xpad, c0p, c0p, (size_t)P, st));
+    TRY(copy_cols(prm->conv[0].w, C, C, w.w0pad, c0p, c0p, (size_t)prm->conv[0].cout, st));
+  }
   for (int l = 0; l < 5; ++l) {                       // conv1..5, BN+ReLU applied on load by the consumer
     const prh_bn_layer& ly = prm->conv[l];
     NTParams p; memset(&p, 0, sizeof(p));
     p.M = P; p.N = ly.cout; p.bias = ly.b; p.C = f16p(z_cat + d.off[l]); p.ldc = cat;
     p.ws_a = w.ws_a; p.ws_b = w.ws_b; p.wprep = w.wprep;
     StatInfo si;
-    if (l == 0) {
+    if (l == 0 && c1_fp32) {
+      hipLaunchKernelGGL((conv_in_b16_kernel<64>), dim3(cdiv(P, 128)), dim3(256), 0, st, ctx, C, ly.w, ly.b, z_cat, (long)cat, P,
+                         training, w.ws_a, w.ws_b);
+      LAUNCH_CHECK();
+      si.count = cdiv(P, 128); si.rows = 128;
+    } else if (l == 0) {
       p.A = f16p(w.xpad); p.lda = c0p; p.W = w.w0pad; p.ldw = c0p; p.K = c0p;
       if (training) TRY((launch_nt_b16<PRO_NONE, EPI_BIAS_STATS, true, true>(p, st, &si)));
       else TRY((launch_nt_b16<PRO_NONE, EPI_BIAS, true, true>(p, st)));
@@ -1740,8 +1767,9 @@ int prh_encoder_backward_bf16(const prh_encoder_params* prm, const float* ctx, i
   if (!a.ok) return fail(PRH_ERR_WORKSPACE, "encoder_backward_bf16: workspace too small (%zu bytes)", workspace_bytes);
   StackDims d = stack_dims(prm->conv, 5);
   const u16* z_cat = sv->z_cat;
-  TRY(cast_b16(ctx, C, C, w.xpad, c0p, c0p, (size_t)P, st));
-  TRY(copy_cols(prm->conv[0].w, C, C, w.w0pad, c0p, c0p, (size_t)prm->conv[0].cout, st));
+  const bool c1_fp32 = conv_in_fp32_ok(C, prm->conv[0].cout);
+  if (!c1_fp32) TRY(cast_b16(ctx, C, C, w.xpad, c0p, c0p, (size_t)P, st));
+  if (!c1_fp32 || d_ctx != nullptr) TRY(copy_cols(prm->conv[0].w, C, C, w.w0pad, c0p, c0p, (size_t)prm->conv[0].cout, st));
 
   // (1) through F = relu(bn(zf)) * m and the pooling: dy_f, dG (over saved.gate), fusion-BN partials
   if (od == 256 || od == 512 || od == 1024 || od == 2048)      // 16-byte accesses: od / 8 threads per row
@@ -1795,7 +1823,15 @@ int prh_encoder_backward_bf16(const prh_encoder_params* prm, const float* ctx, i
     if (gr->conv[l].dw) {
       TNParams t; memset(&t, 0, sizeof(t));
       t.A = f16p(w.dy_cat + o); t.lda = cat; t.P = P; t.Mo = co;
-      if (l == 0) {
+      if (l == 0 && c1_fp32) {       // fp32 context rows as the second operand (VALU reduction)
+        const int rpb = cdiv(cdiv(P, C1_WGRAD_BLOCKS), 4) * 4, nb = cdiv(P, rpb);
+        hipLaunchKernelGGL((conv_in_wgrad_b16_kernel<64>), dim3(nb), dim3(256), 0, st, (const u16*)(w.dy_cat + o), (long)cat,
+                           ctx, C, P, rpb, w.c1part);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv((long)co * C, 256)), dim3(256), 0, st, (const float*)w.c1part, nb, co, C,
+                           gr->conv[0].dw, (long)C);
+        LAUNCH_CHECK();
+      } else if (l == 0) {
         t.B = f16p(w.xpad); t.ldb = c0p; t.Ni = c0p;
         float* out = c0p == C ? gr->conv[0].dw : w.wT;        // padded input: reduce into scratch, drop the pad columns
         TRY((launch_tn_b16<PRO_NONE>(t, w.slab, w.cslab, out, (long)c0p, nullptr, st)));
@@ -2009,7 +2045,7 @@ size_t prh_encoder_fused_workspace_bytes(int B, int N, int planes) {
   return (size_t)B * cdiv(N, mt) * 2048 * sizeof(float) + 256;
 }
 int prh_encoder_fused_forward(const void* image, int planes, int in_channel, int has_proj, const float* ctx, int B,
-                              int N, float* memory, float* fused, float* gfeat, void* workspace,
+                              int N, float* memory, float* fused, float* gfeat, unsigned* saturated, void* workspace,
                               size_t workspace_bytes, int device, void* stream) {
   if (!image || !ctx || B <= 0 || N <= 0 || (planes != 1 && planes != 2) || in_channel < 4 || in_channel > 64)
     return fail(PRH_ERR_ARG, "encoder_fused_forward: bad argument");
@@ -2023,7 +2059,7 @@ int prh_encoder_fused_forward(const void* image, int planes, int in_channel, int
   p.ctx = ctx; p.img = (const char*)image; p.B = B; p.N = N;
   const int mt = planes == 1 ? 64 : 32;
   p.tiles_per_seg = cdiv(N, mt);
-  p.memory = memory; p.fused = fused;
+  p.memory = memory; p.fused = fused; p.sat = saturated;
   if (gfeat != nullptr) {
     Arena a(workspace, workspace_bytes);
     p.pool_ws = a.f((size_t)B * p.tiles_per_seg * 2048);
@@ -2374,7 +2410,7 @@ int prh_posmem_images(const float* xyz, long ldx, const float* w0, const float* 
   if (attr != PRH_OK) return attr;
   static const int n_cu = [] {
     int dev = 0, cu = 256;
-    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
     return cu > 0 ? cu : 256;
   }();
   const long tiles = (rows + 255) / 256;

@@ -131,16 +131,20 @@ class SceneSampleStream:
     (M,3)`` centred, ``target_offset (M,3)`` = resampled ground truth - resampled noisy line
     (:206-207,241).
 
-    Sharding and order (the DistributedSampler + DataLoader semantics, per scene so that a cloud
-    is uploaded once): every epoch the scene order and each scene's sample order are permuted
-    from ``(seed, epoch)`` - identically on every rank - and a scene's samples are dealt
-    round-robin to the ranks, padded by wrap-around so that every rank gets the same number
-    (DistributedSampler's padding).  A rank's samples are pooled over ``mix_scenes`` scenes,
-    shuffled, and cut into batches of ``batch_size``: all ranks yield the same number of
-    batches, so a gradient all-reduce per batch cannot dead-lock.  ``batch_size=None`` keeps one
-    batch per scene.  ``rank`` / ``world_size`` default to the initialised process group (else
-    0 / 1).  Iterating yields dicts of CUDA tensors with a leading sample dimension; ``len()`` is
-    the number of samples this rank sees per epoch."""
+    Sharding and order follow ``DistributedSampler(shuffle=True)`` + ``DataLoader(batch_size)``
+    (train_dist.py:129-140): every epoch ALL (item, candidate) samples of the dataset are permuted from
+    ``(seed, epoch)`` - identically on every rank - the list is padded ONCE, by wrap-around, to a
+    multiple of ``world_size`` (fewer than ``world_size`` duplicates per epoch, as the sampler does) and
+    rank r takes entries r, r + world, ...  What differs from the reference is only the grouping: a
+    rank's samples are collected per scene, so a scene's cloud is parsed and uploaded once per rank
+    that drew samples from it (and not at all by the others) and its contexts come from one kernel
+    call; the scenes are visited in a permuted order, a rank's samples are pooled over ``mix_scenes``
+    scenes, shuffled, and cut into batches of ``batch_size``.  Every rank sees the same NUMBER of
+    samples, hence the same number of batches (all full but the last), so a gradient all-reduce per
+    batch cannot dead-lock.  ``batch_size=None`` keeps one batch per scene (single-rank use: the number
+    of batches then depends on which scenes a rank drew from).  ``rank`` / ``world_size`` default to
+    the initialised process group (else 0 / 1).  Iterating yields dicts of CUDA tensors with a leading
+    sample dimension; ``len()`` is the number of samples this rank sees per epoch."""
 
     def __init__(self, data_root, num_line_points=32, num_context_points=2048, crop_radius=4.0,
                  decay_scale=2.0, split="train", device="cuda", seed=0, batch_size=None, shuffle=True,
@@ -172,11 +176,9 @@ class SceneSampleStream:
                 self.scenes.append((pcd_path, json_path, pairs))
         self.epoch = 0
 
-    def _share(self, n):
-        return -(-n // self.world)             # samples of an n-sample scene each rank takes (padded)
-
     def __len__(self):
-        return sum(self._share(len(s[2])) for s in self.scenes)
+        total = sum(len(s[2]) for s in self.scenes)
+        return -(-total // self.world)           # DistributedSampler.num_samples
 
     def set_epoch(self, epoch):
         self.epoch = int(epoch)
@@ -184,15 +186,18 @@ class SceneSampleStream:
     def _plan(self):
         """[(scene index, this rank's (item, candidate) pairs)] for the current epoch."""
         g = np.random.default_rng([int(self.seed) & 0x7FFFFFFF, self.epoch])
+        flat = [(si, pr) for si, sc in enumerate(self.scenes) for pr in sc[2]]
+        if not flat:
+            return []
+        idx = g.permutation(len(flat)) if self.shuffle else np.arange(len(flat))
+        per = -(-len(flat) // self.world)
+        idx = np.resize(idx, per * self.world)                     # one wrap-around pad for the whole epoch
+        mine = {}
+        for j in idx[self.rank::self.world]:
+            si, pr = flat[int(j)]
+            mine.setdefault(si, []).append(pr)
         order = g.permutation(len(self.scenes)) if self.shuffle else np.arange(len(self.scenes))
-        plan = []
-        for si in order:
-            pairs = self.scenes[si][2]
-            idx = g.permutation(len(pairs)) if self.shuffle else np.arange(len(pairs))
-            per = self._share(len(pairs))
-            idx = np.resize(idx, per * self.world)                 # wrap-around padding
-            plan.append((int(si), [pairs[j] for j in idx[self.rank::self.world]]))
-        return plan
+        return [(int(si), mine.get(int(si), [])) for si in order]
 
     def _scene_samples(self, si, pairs):
         from .context import resample_polyline
@@ -234,7 +239,7 @@ class SceneSampleStream:
                 d = self._scene_samples(si, pairs)
                 pool = d if pool is None else {k: torch.cat([pool[k], d[k]]) for k in keys}
             if (j + 1) % self.mix_scenes == 0 and pool is not None:
-                if self.shuffle:                 # same permutation on every rank: equal pool sizes
+                if self.shuffle:
                     perm = torch.randperm(pool[keys[0]].shape[0], generator=g).to(self.device)
                     pool = {k: pool[k][perm] for k in keys}
                 yield from emit(False)

@@ -19,11 +19,10 @@ hand-written gfx950 kernels:
   a10    DETR decoder layers         ops.linear, ops.attention / attention_block,
                                      ops.add_dropout_layernorm                       (:77-135)
 
-What is left to PyTorch is plumbing: the autograd graph, the FFN dropout, the elementwise adds
-of the positional embeddings and ``torch.stack``.  The ``_lin`` / ``_attn`` / ``_add_norm``
-helpers keep a stock-PyTorch branch for shapes the kernels do not take (widths that are not
-multiples of 4, heads that are not 32 wide); the default model never takes it, and
-``FALLBACKS`` counts every time it is taken (tests/test_model_gpu.py asserts it stays empty).
+What is left to PyTorch is plumbing: the autograd graph and ``torch.stack``.  There is NO
+stock-PyTorch arithmetic branch: shapes the kernels do not take (widths that are not multiples of 4,
+heads that are not 32 wide, a d_model other than 256 in the LayerNorm pass) raise ``RuntimeError`` from
+``ops.py`` / the C ABI, like CPU tensors do.
 """
 from __future__ import annotations
 
@@ -36,13 +35,9 @@ import torch.nn.functional as F
 from . import ops
 
 
-# name -> number of times a stock-PyTorch branch ran instead of a HIP kernel (stays empty for
-# the default LineRefineNet; see the module docstring)
-FALLBACKS = {}
-
-
-def _fell_back(name):
-    FALLBACKS[name] = FALLBACKS.get(name, 0) + 1
+def _warn_saturated(e):
+    import warnings
+    warnings.warn(f"{e} - falling back to the per-layer HIP kernels for this call", RuntimeWarning, stacklevel=3)
 
 
 def _bn_buffers(bn: nn.BatchNorm1d):
@@ -50,38 +45,23 @@ def _bn_buffers(bn: nn.BatchNorm1d):
 
 
 def _attn(q, k, v, heads, dropout_p):
-    """softmax(q k^T / sqrt(d)) v with dropout on the weights: the fused HIP kernel when the
-    shapes fit it (heads of 32 channels, GPU fp32), torch SDPA otherwise."""
-    B, M, C = q.shape
-    if q.is_cuda and C == heads * 32 and heads % 4 == 0 and q.dtype == torch.float32:
-        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if dropout_p > 0.0 else 0
-        return ops.attention(q, k, v, heads, dropout_p, seed)
-    _fell_back("attention")
-    N = k.shape[1]
-    qh = q.reshape(B, M, heads, C // heads).transpose(1, 2)
-    kh = k.reshape(B, N, heads, C // heads).transpose(1, 2)
-    vh = v.reshape(B, N, heads, C // heads).transpose(1, 2)
-    o = F.scaled_dot_product_attention(qh, kh, vh, dropout_p=dropout_p)
-    return o.transpose(1, 2).reshape(B, M, C)
+    """softmax(q k^T / sqrt(d)) v with dropout on the attention weights: the fused HIP kernel pair
+    (heads of 32 channels; anything else raises in ops.attention)."""
+    seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if dropout_p > 0.0 else 0
+    return ops.attention(q, k, v, heads, dropout_p, seed)
 
 
 def _add_norm(x, r, norm, drop, training):
-    """norm(x + dropout(r)): one HIP pass (row f1) for the 256-wide fp32 GPU case the model uses,
-    the stock modules otherwise."""
-    if x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == 256 and norm.elementwise_affine:
-        return ops.add_dropout_layernorm(x, r, norm, drop.p if training else 0.0)
-    _fell_back("add_norm")
-    return norm(x + drop(r))
+    """norm(x + dropout(r)): one HIP pass each way (row f1; 256 channels, affine LayerNorm)."""
+    if not norm.elementwise_affine:
+        raise RuntimeError("pointnet_refine_amd: LayerNorm without affine parameters is not supported by the HIP path")
+    return ops.add_dropout_layernorm(x, r, norm, drop.p if training else 0.0)
 
 
 def _lin(x, weight, bias):
-    """nn.Linear arithmetic on the HIP GEMM cores when the shapes fit them (in/out features
-    multiples of 4, GPU fp32); the 3-wide layers (pos_emb input, regression output) stay on
-    torch.nn.functional.linear."""
-    if x.is_cuda and weight.shape[0] % 4 == 0 and weight.shape[1] % 4 == 0:
-        return ops.linear(x, weight, bias)
-    _fell_back("linear")
-    return F.linear(x, weight, bias)
+    """nn.Linear arithmetic on the HIP GEMM cores (in / out features multiples of 4; ops.linear raises
+    otherwise - the 3-wide layers of the model have their own one-pass kernels)."""
+    return ops.linear(x, weight, bias)
 
 
 class MultiScalePointNetEncoder(nn.Module):
@@ -132,10 +112,13 @@ class MultiScalePointNetEncoder(nn.Module):
             raise RuntimeError(f"Expected 3D (batched) input, but got input of size: {list(x_pm.shape)}")
         bn = self.bn1
         if self._fused_ok(x_pm):
-            _, fused, gfeat = ops.encoder_eval_fused(x_pm, self._param_list(), self._bn_buffer_list(), bn.eps,
-                                                     want_fused=True, want_global=want_global,
-                                                     precision=self.inference_precision)
-            return gfeat, fused
+            try:
+                _, fused, gfeat = ops.encoder_eval_fused(x_pm, self._param_list(), self._bn_buffer_list(), bn.eps,
+                                                         want_fused=True, want_global=want_global,
+                                                         precision=self.inference_precision)
+                return gfeat, fused
+            except ops.FusedSaturation as e:      # activations beyond the fp16 range: the per-layer kernels take it
+                _warn_saturated(e)
         return ops.encoder(x_pm, self._param_list(), self._bn_buffer_list(), want_global, self.training,
                            bn.momentum, bn.eps)
 
@@ -161,17 +144,13 @@ class PositionalEncoding(nn.Module):
         """resid: optional tensor added to the encoding (the decoder's k-input memory + pos,
         src/model.py:123-126) - on the GPU it rides on the second Linear's epilogue."""
         l0, l2 = self.mlp[0], self.mlp[2]
-        if (xyz.is_cuda and xyz.dtype == torch.float32 and l0.in_features == 3
-                and (not xyz.requires_grad or l0.out_features <= 256)
-                and ops.pos_hidden_supported(l0.out_features) and l2.out_features % 4 == 0):
-            # Linear(3,H)+ReLU: one elementwise HIP pass over the points in place (a 3-deep GEMM
-            # is HBM work); Linear(H,H) (+ resid) on the HIP GEMM cores
-            h = ops.pos_hidden(xyz, l0.weight, l0.bias)
-            return ops.linear(h, l2.weight, l2.bias, None, False, resid)
-        _fell_back("pos_hidden")
-        h = F.relu(F.linear(xyz, l0.weight, l0.bias))
-        y = _lin(h, l2.weight, l2.bias)
-        return y if resid is None else y + resid
+        if l0.in_features != 3 or not ops.pos_hidden_supported(l0.out_features) or l2.out_features % 4:
+            raise RuntimeError(f"pointnet_refine_amd: PositionalEncoding({l0.in_features}, {l2.out_features}) is not "
+                               "supported by the HIP path (3-wide points, power-of-two hidden width <= 1024)")
+        # Linear(3,H)+ReLU: one elementwise HIP pass over the points in place (a 3-deep GEMM is HBM
+        # work); Linear(H,H) (+ resid) on the HIP GEMM cores
+        h = ops.pos_hidden(xyz, l0.weight, l0.bias)
+        return ops.linear(h, l2.weight, l2.bias, None, False, resid)
 
 
 class DetrTransformerDecoderLayer(nn.Module):
@@ -234,11 +213,9 @@ class DetrTransformerDecoderLayer(nn.Module):
             o = _attn(qp, k_proj, v_proj, h, pdrop)
         tgt2 = _lin(o, ca.out_proj.weight, ca.out_proj.bias)
         tgt = _add_norm(tgt, tgt2, self.norm2, self.dropout2, self.training)
-        if self.activation is F.relu and tgt.is_cuda:      # ReLU rides on the GEMM epilogue
-            hid = ops.linear(tgt, self.linear1.weight, self.linear1.bias, None, True)
-        else:
-            _fell_back("ffn_activation")
-            hid = self.activation(_lin(tgt, self.linear1.weight, self.linear1.bias))
+        if self.activation is not F.relu:
+            raise RuntimeError("pointnet_refine_amd: the FFN activation is ReLU (src/model.py:95), fused into the GEMM epilogue")
+        hid = ops.linear(tgt, self.linear1.weight, self.linear1.bias, None, True)      # ReLU rides on the epilogue
         tgt2 = _lin(self.dropout(hid), self.linear2.weight, self.linear2.bias)
         tgt = _add_norm(tgt, tgt2, self.norm3, self.dropout3, self.training)
         return tgt
@@ -269,17 +246,23 @@ class LineRefineNet(nn.Module):
             nn.Sequential(nn.Linear(d, 128), nn.ReLU(), nn.Linear(128, 3)) for _ in range(L))
 
     # -- accelerated rows -------------------------------------------------------------------
-    def encode_context(self, context):
-        """context (B,N,4) -> memory (B,N,256): encoder + context_proj (src/model.py:192-194)."""
+    def encode_context(self, context, defer_check=False):
+        """context (B,N,4) -> memory (B,N,256): encoder + context_proj (src/model.py:192-194).
+        defer_check: the fused eval kernel's saturation counter is read by the caller after it has queued
+        the rest of its work (LineRefineNet.forward), not here."""
         enc = self.context_encoder
         if context.dim() != 3:
             raise RuntimeError(f"Expected 3D (batched) input, but got input of size: {list(context.shape)}")
         if enc._fused_ok(context) and tuple(self.context_proj.weight.shape) == (256, 1024):
             # inference: encoder + context_proj as ONE kernel, no activation leaves the chip
-            memory, _, _ = ops.encoder_eval_fused(context, enc._param_list(), enc._bn_buffer_list(), enc.bn1.eps,
-                                                  self.context_proj.weight, self.context_proj.bias,
-                                                  precision=enc.inference_precision)
-            return memory
+            try:
+                memory, _, _ = ops.encoder_eval_fused(context, enc._param_list(), enc._bn_buffer_list(), enc.bn1.eps,
+                                                      self.context_proj.weight, self.context_proj.bias,
+                                                      precision=enc.inference_precision, check=not defer_check)
+                self._fused_pending = defer_check
+                return memory
+            except ops.FusedSaturation as e:
+                _warn_saturated(e)
         _, fused, fused_amax = ops.encoder_with_amax(context, enc._param_list(), enc._bn_buffer_list(), False,
                                                      enc.training, enc.bn1.momentum, enc.bn1.eps)
         return ops.linear(fused, self.context_proj.weight, self.context_proj.bias, fused_amax)
@@ -330,7 +313,9 @@ class LineRefineNet(nn.Module):
                 k_all, v_all = ops.cast_perm_bf16(mempos), ops.cast_perm_bf16(memory)
         else:
             mempos = self.pos_emb(context[:, :, :3], resid=memory)      # memory + pos_mem, (B, N, 256)
-        cat = ops.cat_rows if memory.is_cuda else torch.cat
+        cat = ops.cat_rows
+        if d != 256:
+            raise RuntimeError("pointnet_refine_amd: the decoder kernels are built for d_model = 256 (src/model.py:141)")
         if not fold:
             wk = cat([l.cross_attn.in_proj_weight[d:2 * d] for l in layers])
             bk = cat([l.cross_attn.in_proj_bias[d:2 * d] for l in layers])
@@ -345,39 +330,28 @@ class LineRefineNet(nn.Module):
         else:
             k_all = ops.linear(mempos, wk, bk)                      # (B, N, 6*256)
             v_all = ops.linear(memory, wv, bv)
-        fused = k_all.is_cuda and d == 256
         if fold:
             token = arena = None
-        elif fused:
+        else:
             # the fused attention kernels read column block i of k_all / v_all in place and
             # write dK / dV straight into one gradient buffer each (ops.GradArena): no
             # per-layer K/V tensors, no concatenation of their gradients
             token, arena = ops.kv_token(k_all, v_all, d)
-        else:
-            _fell_back("kv_split")
-            k_split, v_split = k_all.split(d, dim=-1), v_all.split(d, dim=-1)
         current_line_coords = noisy_line.clone()
         all_pred_offsets = []
         for i, (decoder_layer, reg_branch) in enumerate(zip(layers, self.reg_branches)):
             pos_tgt = self.pos_emb(current_line_coords)
             if fold:
                 tgt = decoder_layer.forward_projected(tgt, k_all, v_all, query_pos=pos_tgt, kv_block=("fold", None, i))
-            elif fused:
+            else:
                 tgt = decoder_layer.forward_projected(tgt, k_all, v_all, query_pos=pos_tgt,
                                                       kv_block=(token, arena, i))
-            else:
-                tgt = decoder_layer.forward_projected(tgt, k_split[i], v_split[i], query_pos=pos_tgt)
             r0, r2 = reg_branch[0], reg_branch[2]
-            if tgt.is_cuda and r0.in_features % 4 == 0 and r0.out_features % 4 == 0:
-                hid = ops.linear(tgt, r0.weight, r0.bias, None, True)               # 256 -> 128, ReLU in the epilogue
-            else:
-                _fell_back("reg_head_hidden")
-                hid = F.relu(F.linear(tgt, r0.weight, r0.bias))
-            if hid.is_cuda and ops.linear_small_supported(r2.in_features, r2.out_features):
-                delta_offset = ops.linear_small(hid, r2.weight, r2.bias)            # 128 -> 3: one HBM pass
-            else:
-                _fell_back("reg_head_out")
-                delta_offset = F.linear(hid, r2.weight, r2.bias)
+            hid = ops.linear(tgt, r0.weight, r0.bias, None, True)                   # 256 -> 128, ReLU in the epilogue
+            if not ops.linear_small_supported(r2.in_features, r2.out_features):
+                raise RuntimeError(f"pointnet_refine_amd: regression head Linear({r2.in_features}, {r2.out_features}) "
+                                   "is not supported by the one-pass kernel")
+            delta_offset = ops.linear_small(hid, r2.weight, r2.bias)                # 128 -> 3: one HBM pass
             current_line_coords = current_line_coords + delta_offset      # no detach (H5)
             all_pred_offsets.append(current_line_coords - noisy_line)
         return torch.stack(all_pred_offsets)
@@ -385,6 +359,23 @@ class LineRefineNet(nn.Module):
     def forward(self, context, noisy_line):
         if context.dim() != 3 or noisy_line.dim() != 3:
             raise RuntimeError("LineRefineNet expects context (B,N,4) and noisy_line (B,M,3)")
-        memory = self.encode_context(context)                       # (B, N, 256)
+        self._fused_pending = False
+        memory = self.encode_context(context, defer_check=True)     # (B, N, 256)
         tgt = self.encode_line(noisy_line)                          # (B, M, 256)
-        return self.decode(context, noisy_line, memory, tgt)
+        out = self.decode(context, noisy_line, memory, tgt)
+        if self._fused_pending:
+            # the fused eval kernel ran: read its saturation counter now that the whole forward is queued
+            # (one 4-byte copy; the caller is about to read `out` anyway) and redo the call on the
+            # per-layer kernels if an activation left the fp16 range
+            self._fused_pending = False
+            n = ops.fused_saturation(context.device)
+            if n:
+                _warn_saturated(ops.FusedSaturation(f"{n} activation groups exceeded the fp16 range in the fused eval kernel"))
+                enc, old = self.context_encoder, self.context_encoder.inference_precision
+                enc.inference_precision = None
+                try:
+                    memory = self.encode_context(context)
+                    out = self.decode(context, noisy_line, memory, tgt)
+                finally:
+                    enc.inference_precision = old
+        return out

@@ -62,45 +62,70 @@ def release_workspaces():
 # the matching slice.  Invariant: within a step, a region of the buffer is written either by these
 # Functions or by autograd, never both before the Functions' first write.
 # ------------------------------------------------------------------------------------------
-_GRAD_SINKS = {}          # id(parameter) -> (parameter, gradient tensor)
-_SINK_WRITTEN = set()     # (data_ptr, numel) of the regions written in the current step
+_GRAD_SINKS = {}          # id(parameter) -> (parameter, gradient tensor, id(owner) or None): no strong reference to the owner
+_SINK_WRITTEN = set()     # (data_ptr, numel) of the regions written in the current sinks_active scope
 _SINKS_ACTIVE = False
 _DIRECT = object()
 
 
-def register_grad_sinks(params_and_grads):
+def register_grad_sinks(params_and_grads, owner=None):
+    """owner: whoever registers (a TrainStep); clear_grad_sinks(params, owner) later removes only the
+    entries that are still that owner's - a newer registration for the same parameter survives."""
     for prm, g in params_and_grads:
         if g is not None and g.is_contiguous() and g.dtype == torch.float32:
-            _GRAD_SINKS[id(prm)] = (prm, g)
+            _GRAD_SINKS[id(prm)] = (prm, g, None if owner is None else id(owner))
 
 
-def clear_grad_sinks(params=None):
+def clear_grad_sinks(params=None, owner=None):
     if params is None:
         _GRAD_SINKS.clear()
-    else:
-        for prm in params:
-            _GRAD_SINKS.pop(id(prm), None)
-    _SINK_WRITTEN.clear()
+        return
+    for prm in params:
+        ent = _GRAD_SINKS.get(id(prm))
+        if ent is not None and (owner is None or ent[2] == id(owner)):
+            del _GRAD_SINKS[id(prm)]
 
 
 class sinks_active:
-    """with ops.sinks_active(new_step=True): forward + backward of one (micro-)batch."""
+    """with ops.sinks_active(new_step=True): forward + backward of one (micro-)batch.  The set of regions
+    already written belongs to the scope (saved and restored around it, so a scope opened and closed
+    elsewhere - another TrainStep's __del__, a nested step - cannot make this one overwrite where it
+    should add).  owner: only that owner's sinks are live inside the scope.  preset_written: treat every
+    live sink as already written, i.e. ADD to the buffers' content (gradient accumulation)."""
 
-    def __init__(self, new_step=True):
-        self.new_step = new_step
+    def __init__(self, new_step=True, owner=None, preset_written=False):
+        self.new_step, self.owner, self.preset = new_step, owner, preset_written
 
     def __enter__(self):
-        global _SINKS_ACTIVE
-        self.prev = _SINKS_ACTIVE
-        _SINKS_ACTIVE = bool(_GRAD_SINKS)
+        global _SINKS_ACTIVE, _SINK_WRITTEN, _SINK_OWNER
+        self.prev = (_SINKS_ACTIVE, _SINK_WRITTEN, _SINK_OWNER)
+        _SINK_OWNER = None if self.owner is None else id(self.owner)
+        _SINKS_ACTIVE = any(_SINK_OWNER is None or e[2] == _SINK_OWNER for e in _GRAD_SINKS.values())
         if self.new_step:
-            _SINK_WRITTEN.clear()
+            _SINK_WRITTEN = set()
+            if self.preset:
+                for _, g, own in _GRAD_SINKS.values():
+                    if _SINK_OWNER is None or own == _SINK_OWNER:
+                        _SINK_WRITTEN.add((g.data_ptr(), g.numel()))
+                _SINK_WRITTEN.add("preset")
         return self
 
     def __exit__(self, *exc):
-        global _SINKS_ACTIVE
-        _SINKS_ACTIVE = self.prev
+        global _SINKS_ACTIVE, _SINK_WRITTEN, _SINK_OWNER, LAST_SINK_WRITES
+        LAST_SINK_WRITES = len(_SINK_WRITTEN - {"preset"})
+        _SINKS_ACTIVE, _SINK_WRITTEN, _SINK_OWNER = self.prev
         return False
+
+
+LAST_SINK_WRITES = 0      # regions written through sinks in the scope that closed last (tests)
+
+
+_SINK_OWNER = None
+
+
+def _written(key) -> bool:
+    """True when the region was written in this scope (or the scope adds to everything: preset)."""
+    return key in _SINK_WRITTEN or "preset" in _SINK_WRITTEN
 
 
 class CatRowsFn(torch.autograd.Function):
@@ -125,7 +150,7 @@ class CatRowsFn(torch.autograd.Function):
                 outs.append(gi)
                 continue
             key = (sink.data_ptr(), sink.numel())
-            if key in _SINK_WRITTEN:
+            if _written(key):
                 sink.add_(gi)
             else:
                 _SINK_WRITTEN.add(key)
@@ -145,7 +170,7 @@ def _sink_view(w):
         return None
     base = w._base if w._base is not None else w
     ent = _GRAD_SINKS.get(id(base))
-    if ent is None:
+    if ent is None or (_SINK_OWNER is not None and ent[2] != _SINK_OWNER):
         return None
     g = ent[1]
     if w is base:
@@ -170,7 +195,7 @@ def _grad_buf(sink, shape, dev, need=True):
         return torch.empty(shape, dtype=torch.float32, device=dev), None
     sink = sink.view(shape)
     key = (sink.data_ptr(), sink.numel())
-    if key in _SINK_WRITTEN:
+    if _written(key):
         return torch.empty(shape, dtype=torch.float32, device=dev), sink
     _SINK_WRITTEN.add(key)
     return sink, _DIRECT
@@ -827,17 +852,44 @@ def encoder_with_amax(x_pm, params, buffers, want_global, training, momentum, ep
 # Fused eval-mode encoder (+ context_proj): one kernel, BatchNorm folded (csrc/prh_fused.hpp)
 # ------------------------------------------------------------------------------------------
 _FUSED_IMAGES = {}
+_FUSED_SAT = {}           # device index -> int32[1] counter the fused kernel increments when it clamps an activation
 
 
 def invalidate_fused_images():
-    """Drop the cached weight images of encoder_eval_fused.  The cache is keyed on the tensors'
-    version counters; kernels of this library that write parameters or BatchNorm buffers through
-    raw pointers (the fused Adam step, the training forward's running statistics) call this."""
+    """Drop the cached weight images of encoder_eval_fused.  Not needed for correctness - the cache key
+    carries a device-side fingerprint of every tensor the image is made of, so `p.data.copy_()`, EMA
+    updates, broadcasts and raw-pointer writers are all seen - but it frees the images' memory."""
     _FUSED_IMAGES.clear()
 
 
 def _tensor_key(t):
     return (t.data_ptr(), t._version, tuple(t.shape))
+
+
+def _fingerprint(tensors):
+    """L2 norms of the tensors, computed on the device (one multi-tensor launch) and read back in one
+    copy: part of the image cache key.  Version counters miss writes through `.data` and through raw
+    pointers; the values themselves do not."""
+    ts = [t.detach() for t in tensors if t is not None and t.is_floating_point()]
+    return tuple(torch.stack(torch._foreach_norm(ts)).tolist())
+
+
+class FusedSaturation(RuntimeError):
+    """The fused eval kernel clamped an activation at the fp16 maximum: its result was discarded."""
+
+
+def fused_saturation(device, reset=True) -> int:
+    """Number of activation groups the fused eval kernel has clamped at 65504 on `device` since the last
+    reset (synchronises).  The kernel carries activations between layers as fp16 planes; post-BatchNorm
+    values of a trained checkpoint are O(1), anything that reaches the clamp is flagged here."""
+    dev = torch.device(device)
+    t = _FUSED_SAT.get(dev.index if dev.index is not None else torch.cuda.current_device())
+    if t is None:
+        return 0
+    n = int(t.item())
+    if n and reset:
+        t.zero_()
+    return n
 
 
 def encoder_eval_fused_supported(params, proj_w=None):
@@ -851,13 +903,15 @@ def encoder_eval_fused_supported(params, proj_w=None):
 
 
 def encoder_eval_fused(x_pm, params, buffers, eps, proj_w=None, proj_b=None, want_fused=False, want_global=False,
-                       precision="fp32"):
+                       precision="fp32", check=True):
     """Eval-mode MultiScalePointNetEncoder (+ context_proj) in ONE kernel with BatchNorm folded into
     the weights (src/model.py:39-62 in eval mode, :194): x (B,N,C) -> (memory (B,N,256) or None,
     fused (B,N,1024) or None, global_feat (B,2048) or None).  precision "fp32": two fp16 planes,
     three products, fp32-level error; "fp16": one fp16 plane (BASELINE config 5).  Inference only
     (no autograd).  The folded / split weight image is prepared once per set of weights and cached
-    (keyed on the tensors' addresses and version counters)."""
+    (keyed on the tensors' addresses, version counters and a device-side fingerprint of their values).
+    check=True: raises FusedSaturation when an activation exceeded the fp16 range inside the kernel (one
+    4-byte read back); check=False leaves that to a later ops.fused_saturation(device) of the caller."""
     _req_gpu_f32(x_pm, "input")
     if precision not in ("fp32", "fp16"):
         raise ValueError("encoder_eval_fused: precision must be 'fp32' or 'fp16'")
@@ -876,7 +930,8 @@ def encoder_eval_fused(x_pm, params, buffers, eps, proj_w=None, proj_b=None, wan
     lib = L.lib()
     key = (dev.index, planes, float(eps), tuple(_tensor_key(t) for t in params),
            tuple(_tensor_key(t) for t in buffers if t.is_floating_point()),
-           None if proj_w is None else (_tensor_key(proj_w), None if proj_b is None else _tensor_key(proj_b)))
+           None if proj_w is None else (_tensor_key(proj_w), None if proj_b is None else _tensor_key(proj_b)),
+           _fingerprint(list(params) + list(buffers) + [proj_w, proj_b]))
     slot = (dev.index, planes, id(params[0]), proj_w is not None)
     ent = _FUSED_IMAGES.get(slot)
     if ent is None or ent[0] != key:
@@ -896,9 +951,18 @@ def encoder_eval_fused(x_pm, params, buffers, eps, proj_w=None, proj_b=None, wan
     fused = torch.empty((B, N, 1024), dtype=torch.float32, device=dev) if want_fused else None
     gfeat = torch.empty((B, 2048), dtype=torch.float32, device=dev) if want_global else None
     ws = _ws(dev, lib.prh_encoder_fused_workspace_bytes(B, N, planes)) if want_global else None
+    sat = _FUSED_SAT.get(dev.index)
+    if sat is None:
+        sat = _FUSED_SAT[dev.index] = torch.zeros(1, dtype=torch.int32, device=dev)
     L.check(lib.prh_encoder_fused_forward(C.c_void_p(img.data_ptr() + off), planes, Cin, int(proj_w is not None), _p(x),
-                                          B, N, _p(memory), _p(fused), _p(gfeat), _p(ws), ws.numel() if ws is not None else 0,
-                                          dev.index, _stream(dev)), "prh_encoder_fused_forward")
+                                          B, N, _p(memory), _p(fused), _p(gfeat), _p(sat), _p(ws),
+                                          ws.numel() if ws is not None else 0, dev.index, _stream(dev)),
+            "prh_encoder_fused_forward")
+    if check:
+        n = fused_saturation(dev)
+        if n:
+            raise FusedSaturation(f"encoder_eval_fused: {n} activation groups exceeded the fp16 range (65504) inside the "
+                                  "fused kernel; use the per-layer kernels (inference_precision=None) for these weights")
     return memory, fused, gfeat
 
 

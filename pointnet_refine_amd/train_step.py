@@ -27,18 +27,25 @@ from . import ops
 
 
 class FlatGrads:
-    """All parameter gradients as views into one buffer; one collective per step."""
+    """All parameter gradients as views into one buffer; one collective per step.  Every tensor starts
+    on a 16-byte boundary (offsets padded to multiples of 4 elements; the padding stays zero): the
+    parameters that FlatAdam re-homes with this same layout keep the alignment the kernels' 16-byte
+    loads and LDS-DMA need (the 3-wide regression biases would otherwise shift everything behind them)."""
+
+    ALIGN = 4
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
-        p0 = self.params[0]
-        self.flat = torch.zeros(n, dtype=p0.dtype, device=p0.device)
-        self.views = []
+        self.offsets = []
         off = 0
         for p in self.params:
-            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off = -(-off // self.ALIGN) * self.ALIGN
+            self.offsets.append(off)
             off += p.numel()
+        n = -(-off // self.ALIGN) * self.ALIGN
+        p0 = self.params[0]
+        self.flat = torch.zeros(n, dtype=p0.dtype, device=p0.device)
+        self.views = [self.flat[o:o + p.numel()].view_as(p) for o, p in zip(self.offsets, self.params)]
         self.rebind()
 
     def rebind(self):
@@ -50,39 +57,76 @@ class FlatGrads:
         self.flat.zero_()
         self.rebind()
 
-    def all_reduce_mean(self, world_size: int, group=None):
-        # runs whenever a process group exists (also at world_size 1 under torchrun, so the
-        # single-GPU launch exercises the same RCCL calls as the 8-GPU one)
-        if dist.is_available() and dist.is_initialized():
-            n = dist.get_world_size(group)
-            if world_size not in (None, 1, n):
-                raise RuntimeError(f"TrainStep: world_size={world_size} disagrees with the process group ({n} ranks)")
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+    def offset_of(self, param) -> int:
+        """Element offset of `param`'s gradient inside the flat buffer."""
+        for p, off in zip(self.params, self.offsets):
+            if p is param:
+                return off
+        raise KeyError("parameter is not in this gradient buffer")
+
+    def all_reduce_mean(self, world_size: int, group=None, start: int = 0, stop=None, async_op: bool = False):
+        """Mean over the group of flat[start:stop] (default: everything).  Runs whenever a process group
+        exists (also at world_size 1 under torchrun, so the single-GPU launch exercises the same RCCL
+        calls as the 8-GPU one).  async_op: returns a handle whose wait() also applies the 1/n."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return None
+        n = dist.get_world_size(group)
+        if world_size not in (None, 1, n):
+            raise RuntimeError(f"TrainStep: world_size={world_size} disagrees with the process group ({n} ranks)")
+        part = self.flat[start:stop]
+        if part.numel() == 0:
+            return None
+        work = dist.all_reduce(part, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        if not async_op:
             if n > 1:                  # the mean DDP takes (train_dist.py:147), whatever the caller passed
-                self.flat.div_(n)
+                part.div_(n)
+            return None
+
+        class _Pending:
+            def wait(self_inner):
+                work.wait()
+                if n > 1:
+                    part.div_(n)
+        return _Pending()
 
 
 class FlatBuffers:
-    """BatchNorm running statistics packed for the rank-0 broadcast DDP performs."""
+    """BatchNorm running statistics for the rank-0 broadcast DDP performs (broadcast_buffers=True,
+    train_dist.py:143-147).  The floating buffers are RE-HOMED as views into one flat fp32 buffer and
+    the `num_batches_tracked` counters into one flat int64 buffer (the kernels write them through raw
+    pointers, so nothing else changes): the per-step exchange is two collectives on tensors that already
+    exist - no concatenation, no scatter back."""
 
     def __init__(self, module: torch.nn.Module):
         self.bufs = [b for _, b in module.named_buffers() if b.is_floating_point()]
         self.ints = [b for _, b in module.named_buffers() if not b.is_floating_point()]
+        self.flat = self._rehome(self.bufs, torch.float32)
+        self.flat_int = self._rehome(self.ints, torch.int64)
+
+    @staticmethod
+    def _rehome(tensors, dtype):
+        tensors = [t for t in tensors if t.dtype == dtype]
+        if not tensors:
+            return None
+        n = sum(t.numel() for t in tensors)
+        flat = torch.empty(n, dtype=dtype, device=tensors[0].device)
+        off = 0
+        with torch.no_grad():
+            for t in tensors:
+                k = t.numel()
+                flat[off:off + k].copy_(t.reshape(-1))
+                t.data = flat[off:off + k].view(t.shape)
+                off += k
+        return flat
 
     def broadcast(self, group=None):
-        if not self.bufs:
-            return
-        flat = torch.cat([b.reshape(-1) for b in self.bufs])
-        dist.broadcast(flat, 0, group=group)
-        off = 0
-        for b in self.bufs:
-            b.copy_(flat[off:off + b.numel()].view_as(b))
-            off += b.numel()
-        if self.ints:
-            fi = torch.stack([b.reshape(()) for b in self.ints])
-            dist.broadcast(fi, 0, group=group)
-            for i, b in enumerate(self.ints):
-                b.copy_(fi[i])
+        if self.flat is not None:
+            dist.broadcast(self.flat, 0, group=group)
+        if self.flat_int is not None:
+            dist.broadcast(self.flat_int, 0, group=group)
+        for b in self.bufs + self.ints:          # anything of another dtype stayed where it was
+            if b.dtype not in (torch.float32, torch.int64):
+                dist.broadcast(b, 0, group=group)
 
 
 def deep_supervision_l1(out, target, denom=None, geometry=None, points=None):
@@ -104,14 +148,12 @@ class FlatAdam:
         self.grads = grads
         self.param_groups = [{"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": weight_decay,
                               "params": grads.params}]
-        flat = torch.empty_like(grads.flat)
-        off = 0
+        flat = torch.zeros_like(grads.flat)
         with torch.no_grad():
-            for p in grads.params:
+            for p, off in zip(grads.params, grads.offsets):
                 n = p.numel()
                 flat[off:off + n].copy_(p.detach().reshape(-1))
                 p.data = flat[off:off + n].view_as(p)          # parameters now live in the flat buffer
-                off += n
         self.flat = flat
         self.exp_avg = torch.zeros_like(flat)
         self.exp_avg_sq = torch.zeros_like(flat)
@@ -156,8 +198,8 @@ class TrainStep:
         self.chunk = decoder_chunk
         self.world, self.group = world_size, group
         self.grads = FlatGrads(model.parameters())
-        from . import ops
-        ops.register_grad_sinks(zip(self.grads.params, self.grads.views))
+        self._sinks_on = False
+        self._ensure_sinks()
         self.opt = optimizer if optimizer is not None else FlatAdam(self.grads, lr=lr)
         distributed = dist.is_available() and dist.is_initialized()
         self.bufs = FlatBuffers(model) if (distributed and broadcast_buffers) else None
@@ -167,15 +209,41 @@ class TrainStep:
             return deep_supervision_l1(out, target, denom, self.geometry, points)
         return self.loss_fn(out, target, denom)
 
-    def forward_backward(self, context, noisy_line, target):
-        """One (micro-batched) forward + loss + backward.  The gradient buffer must be zero on
-        entry (grads.zero()): inside, the library's backward kernels write parameter gradients
-        straight into it (ops gradient sinks) instead of going through autograd's accumulation."""
+    def forward_backward(self, context, noisy_line, target, accumulate: bool = False, decoder_done=None):
+        """One (micro-batched) forward + loss + backward into the flat gradient buffer.  Inside, the
+        library's backward kernels write parameter gradients straight into the buffer (ops gradient
+        sinks) instead of going through autograd's accumulation: with accumulate=False (default) the
+        first contribution to a tensor OVERWRITES what the buffer held (the buffer should be zero on
+        entry: grads.zero(), as __call__ does); accumulate=True ADDS this call's gradients to the
+        buffer's content - gradient accumulation over several calls before one optimiser step.
+        decoder_done: called (no arguments) once the gradients of every decoder-side parameter are
+        final and only the encoder-side backward is left (see decoder_grad_offset)."""
         from . import ops
-        with ops.sinks_active(new_step=True):
-            return self._forward_backward(context, noisy_line, target)
+        self._ensure_sinks()
+        with ops.sinks_active(new_step=True, owner=self, preset_written=accumulate):
+            return self._forward_backward(context, noisy_line, target, decoder_done)
 
-    def _forward_backward(self, context, noisy_line, target):
+    def decoder_grad_offset(self) -> int:
+        """flat[offset:] holds the gradients of pos_emb, decoder_layers and reg_branches - final as soon as
+        the decoder micro-batches are done (parameter order of LineRefineNet: context_encoder,
+        context_proj, point_mlp, then these).  len(flat) when the model has no such split."""
+        m = self.model
+        first = getattr(getattr(m, "pos_emb", None), "mlp", None)
+        if first is None or not hasattr(m, "decode"):
+            return self.grads.flat.numel()
+        names = [n for n, p in m.named_parameters() if p.requires_grad]
+        i0 = next((i for i, n in enumerate(names) if n.startswith("pos_emb.")), None)
+        if i0 is None or any(n.split(".")[0] in ("context_encoder", "context_proj", "point_mlp") for n in names[i0:]):
+            return self.grads.flat.numel()
+        return self.grads.offsets[i0]
+
+    def _ensure_sinks(self):
+        from . import ops
+        if not getattr(self, "_sinks_on", False):
+            ops.register_grad_sinks(zip(self.grads.params, self.grads.views), owner=self)
+            self._sinks_on = True
+
+    def _forward_backward(self, context, noisy_line, target, decoder_done=None):
         m = self.model
         if self.loss_fn is deep_supervision_l1:
             if self.geometry is None:
@@ -186,6 +254,8 @@ class TrainStep:
             out = m(context, noisy_line)
             loss = self._loss(out, target, float(out.numel()), float(target.numel() // 3))
             loss.backward()
+            if decoder_done is not None:
+                decoder_done()
             if self.keep_out:
                 self.last_out = out.detach()
             return loss.detach()
@@ -211,6 +281,8 @@ class TrainStep:
             if outs is not None:
                 outs.append(out.detach())
             del out, loss_c, mem_c, tgt_c
+        if decoder_done is not None:        # pos_emb / decoder_layers / reg_branches gradients are final
+            decoder_done()
         torch.autograd.backward([memory, tgt0], [d_memory, d_tgt0])
         if outs is not None:
             self.last_out = torch.cat(outs, dim=1)
@@ -229,12 +301,13 @@ class TrainStep:
                 pass
             self._seed = None
         self._graph, self._static, self._static_loss = None, None, None
-        if getattr(self, "grads", None) is not None:
+        if getattr(self, "grads", None) is not None and getattr(self, "_sinks_on", False):
             try:
                 from . import ops
-                ops.clear_grad_sinks(self.grads.params)
+                ops.clear_grad_sinks(self.grads.params, owner=self)      # only the entries this step registered
             except Exception:
                 pass
+            self._sinks_on = False
 
     def __del__(self):
         self.close()
@@ -293,9 +366,23 @@ class TrainStep:
                 dst.copy_(src)
             self._graph.replay()
             loss = self._static_loss
+            self.grads.all_reduce_mean(self.world, self.group)
         else:
             self.grads.zero()
-            loss = self.forward_backward(context, noisy_line, target)
-        self.grads.all_reduce_mean(self.world, self.group)
+            # the gradient exchange of the decoder side (26 MB of the 38.8 MB) is issued as soon as the
+            # decoder micro-batches are done and runs under the encoder's backward - what DDP's bucket
+            # hooks do for the reference (train_dist.py:147,188); the encoder side follows at the end
+            pending = []
+            split = self.decoder_grad_offset() if (dist.is_available() and dist.is_initialized()) else None
+
+            def decoder_done():
+                h = self.grads.all_reduce_mean(self.world, self.group, start=split, async_op=True)
+                if h is not None:
+                    pending.append(h)
+            overlap = split is not None and 0 < split < self.grads.flat.numel()
+            loss = self.forward_backward(context, noisy_line, target, decoder_done=decoder_done if overlap else None)
+            self.grads.all_reduce_mean(self.world, self.group, stop=split if overlap else None)
+            for h in pending:
+                h.wait()
         self.opt.step()
         return loss

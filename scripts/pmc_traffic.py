@@ -13,15 +13,16 @@ import sys
 import hashlib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL_SOURCES = ("prh_gemm.hpp", "prh_gemm_s3.hpp", "prh_gemm_h2.hpp", "prh_b16.hpp", "prh_attn16.hpp", "prh_fused.hpp")
-
-
 def kernel_sources_sha():
-    """Fingerprint of the kernel sources the counters belong to: bench.py drops the lookup
-    (traffic null) when the tree's fingerprint differs from the one recorded here."""
+    """Fingerprint of EVERY file of csrc/ (the file set _lib._SOURCES compiles), the same function as
+    bench.kernel_sources_sha: bench.py drops the lookup (traffic null) when the tree's fingerprint
+    differs from the one recorded here."""
     h = hashlib.sha256()
-    for f in KERNEL_SOURCES:
-        h.update(open(os.path.join(ROOT, "pointnet_refine_amd", "csrc", f), "rb").read())
+    d_ = os.path.join(ROOT, "pointnet_refine_amd", "csrc")
+    for f in sorted(os.listdir(d_)):
+        if f.endswith((".hpp", ".h", ".hip")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d_, f), "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -69,7 +69,7 @@ def _worker(rank, world, port, out):
     flat = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
     dist.all_reduce(flat)
     flat /= world
-    got = step.grads.flat
+    got = torch.cat([v.reshape(-1) for v in step.grads.views])      # the flat buffer pads tensors to 16-byte boundaries
     weights = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
     gathered = [torch.zeros_like(weights) for _ in range(world)]
     dist.all_gather(gathered, weights)

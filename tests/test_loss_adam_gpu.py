@@ -210,15 +210,15 @@ def test_gradient_sinks_match_autograd_accumulation(chunk):
     torch.manual_seed(5)                     # dropout seeds are drawn from torch's CPU generator
     sa.grads.zero()
     la = sa.forward_backward(ctx, noisy, target)
-    assert len(ops._SINK_WRITTEN) >= len(sa.grads.params) - 8, len(ops._SINK_WRITTEN)   # nearly every parameter went direct
-    assert not ops._SINKS_ACTIVE
+    assert ops.LAST_SINK_WRITES >= len(sa.grads.params) - 8, ops.LAST_SINK_WRITES   # nearly every parameter went direct
+    assert not ops._SINKS_ACTIVE and not ops._SINK_WRITTEN       # the bookkeeping belongs to the scope
     # plain autograd on the twin: no TrainStep, no sinks; poisoned .grad would show an overwrite
     torch.manual_seed(5)
     sb = TrainStep(b, decoder_chunk=chunk)
     ops.clear_grad_sinks(sb.grads.params)    # registered by the constructor: take them away again
     sb.grads.zero()
     lb = sb.forward_backward(ctx, noisy, target)
-    assert len(ops._SINK_WRITTEN) == 0
+    assert ops.LAST_SINK_WRITES == 0
     assert abs(float(la) - float(lb)) < 1e-6
     for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
         assert p.grad is not None and q.grad is not None, k
@@ -233,3 +233,50 @@ def test_gradient_sinks_match_autograd_accumulation(chunk):
         assert maxdiff(p.grad, q.grad) <= 2e-6 * scale + 1e-9, k
     sa.close()
     assert not any(id(p) in ops._GRAD_SINKS for p in sa.grads.params)
+
+
+def test_gradient_accumulation_and_step_ownership():
+    """(a) forward_backward(accumulate=True) ADDS to the flat buffer - two micro-batches
+    then one optimiser step see the sum of both gradients, for sinked and autograd-handled parameters
+    alike; (b) a second TrainStep on the same model takes the sinks over, and dropping the FIRST one
+    afterwards must not remove the second one's registration (its gradients keep going direct)."""
+    import gc
+    from pointnet_refine_amd import ops
+    from pointnet_refine_amd.model import LineRefineNet
+    from pointnet_refine_amd.synth import synthetic_batch
+    from pointnet_refine_amd.train_step import TrainStep
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(2)
+    m = LineRefineNet().cuda().train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        if isinstance(mod, torch.nn.MultiheadAttention):
+            mod.dropout = 0.0
+    b1 = synthetic_batch(8, 256, dev, seed=1)
+    b2 = synthetic_batch(8, 256, dev, seed=2)
+    st = TrainStep(m, torch.optim.SGD(m.parameters(), lr=0.0), decoder_chunk=4)
+    st.grads.zero(); st.forward_backward(*b1); g1 = st.grads.flat.clone()
+    st.grads.zero(); st.forward_backward(*b2); g2 = st.grads.flat.clone()
+    st.grads.zero()
+    st.forward_backward(*b1)
+    st.forward_backward(*b2, accumulate=True)
+    want = g1 + g2
+    assert float((st.grads.flat - want).abs().max()) <= 2e-6 * float(want.abs().max())
+    st.forward_backward(*b2)                                   # default: the step starts over
+    assert float((st.grads.flat - g2).abs().max()) <= 2e-6 * float(g2.abs().max())
+    # (b) ownership
+    st2 = TrainStep(m, torch.optim.SGD(m.parameters(), lr=0.0), decoder_chunk=4)
+    del st
+    gc.collect()
+    assert all(id(p) in ops._GRAD_SINKS for p in st2.grads.params)
+    st2.grads.zero()
+    st2.forward_backward(*b1)
+    assert ops.LAST_SINK_WRITES >= len(st2.grads.params) - 8
+    assert float((st2.grads.flat - g1).abs().max()) <= 2e-6 * float(g1.abs().max())
+    st2.close()
+    assert not any(id(p) in ops._GRAD_SINKS for p in st2.grads.params)
+    st2.grads.zero()
+    st2.forward_backward(*b1)                                  # a closed step re-registers when used again
+    assert ops.LAST_SINK_WRITES >= len(st2.grads.params) - 8
+    st2.close()

@@ -255,16 +255,15 @@ def test_decoder_layer_standalone_call_contract():
 
 
 def test_default_model_never_takes_a_stock_pytorch_branch():
-    """model._lin/_attn/_add_norm keep stock-PyTorch branches for shapes the kernels reject;
-    the default LineRefineNet must never take one: a train step and an eval forward leave
-    model.FALLBACKS empty, and the attention / LayerNorm / Linear arithmetic never reaches
-    torch's own kernels (F.linear, SDPA, F.layer_norm patched to raise)."""
+    """The product model has no stock-PyTorch arithmetic branch (unsupported shapes raise): a train
+    step and an eval forward never reach torch's own Linear / attention / LayerNorm / BatchNorm / conv
+    kernels (patched to raise), and a shape the kernels do not take raises RuntimeError instead of
+    quietly running on torch."""
     from pointnet_refine_amd import model as M
     import torch.nn.functional as F
     m = _model(P.linerefine_state_dict(0))
     ctx, noisy, target = P.synth_batch(4, 128, 4, 32, seed=2)
     ctx, noisy, target = ctx.cuda(), noisy.cuda(), target.cuda()
-    M.FALLBACKS.clear()
 
     def boom(name):
         def f(*a, **k):
@@ -286,5 +285,11 @@ def test_default_model_never_takes_a_stock_pytorch_branch():
     finally:
         for n, f in saved.items():
             setattr(F, n, f)
-    assert M.FALLBACKS == {}, M.FALLBACKS
     assert all(p.grad is not None for p in m.parameters())
+    assert not hasattr(M, "FALLBACKS")
+    # shapes outside the kernels' range fail loudly
+    odd = M.DetrTransformerDecoderLayer(d_model=192, nhead=8, dim_feedforward=256, dropout=0.0).cuda()
+    with pytest.raises(RuntimeError):
+        odd(torch.randn(2, 32, 192, device="cuda"), torch.randn(2, 64, 192, device="cuda"))
+    with pytest.raises(RuntimeError):
+        M.PositionalEncoding(in_dim=2, out_dim=256).cuda()(torch.randn(2, 8, 2, device="cuda"))
