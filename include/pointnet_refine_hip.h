@@ -236,8 +236,12 @@ int prh_linear_forward_ex(const float* x, long ldx, const float* w, const float*
  * positional-encoding MLP - and an optional device scalar w_amax = max|w|. */
 int prh_linear_forward_full(const float* x, long ldx, const float* w, const float* b, const float* resid,
                             long ldres, float* y, int rows, int k, int n, int relu, const float* x_amax,
-                            const float* w_amax, void* workspace, size_t workspace_bytes, int device,
-                            void* stream);
+                            const float* w_amax, float dropout_p, unsigned dropout_seed, void* workspace,
+                            size_t workspace_bytes, int device, void* stream);
+/* dropout_p > 0: y = dropout(act(x W^T + b + resid)) with the keep decision a counter hash of
+ * (dropout_seed, row, column) and survivors scaled by 1 / (1 - p) - the FFN hidden layer of the decoder
+ * (src/model.py:131) leaves the GEMM epilogue already dropped out; no mask tensor exists, the backward
+ * reads the decision off the output (prh_relu_mask_absmax with scale = 1 / (1 - p)). */
 
 /* Operand maxima for the split-fp16 cores, measured once by the caller and handed to every GEMM
  * that reads the operand (x_amax / w_amax / dy_amax arguments; NULL = the launch measures it):
@@ -251,8 +255,9 @@ int prh_operand_absmax(const float* x, long ld, long rows, int cols, float* out,
  * activation; :162-166 reg_branches): out = y > 0 ? dy : 0 and amax_out[0] = max|out| (the operand
  * maximum of the split-fp16 backward GEMMs) in one pass.  n elements, n % 4 == 0, contiguous.
  * Workspace: prh_operand_absmax_workspace_bytes(). */
-int prh_relu_mask_absmax(const float* dy, const float* y, float* out, long n, float* amax_out, void* workspace,
-                         size_t workspace_bytes, int device, void* stream);
+int prh_relu_mask_absmax(const float* dy, const float* y, float* out, long n, float scale, float* amax_out,
+                         void* workspace, size_t workspace_bytes, int device, void* stream);
+/* scale: 1 for a plain ReLU; 1 / (1 - p) when y came out of a ReLU + dropout epilogue (out = y > 0 ? dy * scale : 0). */
 int prh_linear_uses_operand_maxima(int rows, int k, int n);
 
 /* First layer of the positional-encoding MLP (src/model.py:64-75, nn.Linear(3, hidden) + ReLU)

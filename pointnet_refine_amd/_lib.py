@@ -157,7 +157,7 @@ def _bind(lib):
     lib.prh_linear_forward_ex.restype = i
     lib.prh_linear_forward_ex.argtypes = [vp, lg, vp, vp, vp, i, i, i, i, vp, vp, sz, i, vp]
     lib.prh_linear_forward_full.restype = i
-    lib.prh_linear_forward_full.argtypes = [vp, lg, vp, vp, vp, lg, vp, i, i, i, i, vp, vp, vp, sz, i, vp]
+    lib.prh_linear_forward_full.argtypes = [vp, lg, vp, vp, vp, lg, vp, i, i, i, i, vp, vp, f, C.c_uint, vp, sz, i, vp]
     lib.prh_operand_absmax_workspace_bytes.restype = sz
     lib.prh_operand_absmax_workspace_bytes.argtypes = []
     lib.prh_operand_absmax.restype = i
@@ -224,7 +224,7 @@ def _bind(lib):
     lib.prh_attn_fold_forward.restype = i
     lib.prh_attn_fold_forward.argtypes = [vp, lg, vp, vp, vp, lg, vp, lg, vp, vp, lg, i, i, i, i, C.c_float, i, vp]
     lib.prh_relu_mask_absmax.restype = i
-    lib.prh_relu_mask_absmax.argtypes = [vp, vp, vp, lg, vp, vp, sz, i, vp]
+    lib.prh_relu_mask_absmax.argtypes = [vp, vp, vp, lg, f, vp, vp, sz, i, vp]
     lib.prh_set_gemm_mode.restype = i
     lib.prh_set_gemm_mode.argtypes = [i]
     lib.prh_attn_backward_ex.restype = i

@@ -41,6 +41,10 @@ enum {
   F_STORE_GATE = 16,  // EPI_GATE: also store m = 0.5+0.5*sigmoid() to C2
   F_E1_ROWVEC = 32,   // EPI_DGRAD: E1 is one value per row (E1[row*lde1]), not a matrix
   F_RESID = 64,       // EPI_BIAS: C = acc + bias + E1 (residual input, before the optional ReLU)
+  F_DROPOUT = 256,    // EPI_BIAS: after the optional ReLU, C = keep(row, col) ? C * drop_scale : 0 - the dropout of
+                      //   the FFN hidden layer (src/model.py:131: linear2(dropout(activation(linear1(tgt))))) on the
+                      //   epilogue that produces it; the decision is a counter hash of (seed, row, column), so no
+                      //   mask is stored: the backward reads it off the output (C > 0)
   F_POOL = 128,       // EPI_GATE (vector epilogue): per 128-row wave tile and column, the largest output,
                       //   the tile-local row of its FIRST occurrence and the column sum -> ws_a / ws_c (int
                       //   bits) / ws_b [2*row_tiles][N]: the dual pooling (src/model.py:58-60) rides on the
@@ -66,7 +70,22 @@ struct NTParams {
   char* wprep;                   // scratch for the split weight image (null: fp32 MFMA core)
   const float* amaxA;            // fp16-plane cores: largest |pro(A)| (device; null: the launch
   const float* amaxW;            //   measures it) and largest |W| (set by the launch)
+  unsigned drop_seed, drop_thresh;    // F_DROPOUT: host seed, p * 2^32
+  float drop_scale;                   //   1 / (1 - p)
+  const unsigned* seed_src;           //   optional device word mixed into the seed (graph replays)
 };
+
+// dropout decision of element (row, col): counter hash, the same for every kernel that needs it again
+__device__ __forceinline__ bool epi_keep(unsigned seed, unsigned row, unsigned col, unsigned thresh) {
+  unsigned x = seed ^ (row * 0x9E3779B1u) ^ (col * 0x85EBCA77u);
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x >= thresh;
+}
+__device__ __forceinline__ unsigned epi_seed(const NTParams& p) {
+  if (p.seed_src == nullptr) return p.drop_seed;
+  const unsigned w = __hip_atomic_load(p.seed_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return p.drop_seed ^ (__builtin_amdgcn_readfirstlane(w) * 0x9E3779B9u);
+}
 
 constexpr int BM = 128, BN = 128, BK = 32;
 
@@ -128,6 +147,7 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[MT][NT], const NTParam
   float* __restrict__ C2b = p.C2 != nullptr ? p.C2 + (size_t)rbase * p.ldc2 : nullptr;
   const int ldc = (int)p.ldc, lde1 = (int)p.lde1, ldc2 = (int)p.ldc2;
   const int mrows = p.M - rbase;   // rows of this wave tile that exist
+  const unsigned dseed = (EPI == EPI_BIAS && (p.flags & F_DROPOUT) != 0) ? epi_seed(p) : 0u;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int col = cbase + nt * 32 + l31;
@@ -144,6 +164,8 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[MT][NT], const NTParam
           float v = acc[mt][nt][r] + bias;
           if (EPI == EPI_BIAS && (p.flags & F_RESID) != 0 && lr < mrows && cok) v += Eb[lr * lde1 + col];
           if ((p.flags & F_RELU_OUT) != 0) v = fmaxf(v, 0.f);
+          if (EPI == EPI_BIAS && (p.flags & F_DROPOUT) != 0)
+            v = epi_keep(dseed, (unsigned)(rbase + lr), (unsigned)col, p.drop_thresh) ? v * p.drop_scale : 0.f;
           acc[mt][nt][r] = v;
           if (lr < mrows && cok) {
             Cb[lr * ldc + col] = v;
@@ -432,6 +454,7 @@ __device__ __forceinline__ void nt_epilogue_vec(ACC& acc, const NTParams& p, int
 
   const bool mask = (p.flags & F_MASK) != 0, accum = (p.flags & F_ACCUM) != 0;
   const bool resid = EPI == EPI_BIAS && (p.flags & F_RESID) != 0;
+  const unsigned dseed = (EPI == EPI_BIAS && (p.flags & F_DROPOUT) != 0) ? epi_seed(p) : 0u;
   const bool need_z = (EPI == EPI_DGRAD && (mask || (p.flags & F_STATS) != 0)) || EPI == EPI_GATE || resid;
   float4 s1 = zero4(), s2 = zero4();
   const bool pool = EPI == EPI_GATE && (p.flags & F_POOL) != 0;
@@ -538,6 +561,13 @@ __device__ __forceinline__ void nt_epilogue_vec(ACC& acc, const NTParams& p, int
         if (resid) { v.x += z.x; v.y += z.y; v.z += z.z; v.w += z.w; }
         if ((p.flags & F_RELU_OUT) != 0) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        if (EPI == EPI_BIAS && (p.flags & F_DROPOUT) != 0) {
+          const unsigned rw = (unsigned)(rbase + lr), c0 = (unsigned)col4;
+          v.x = epi_keep(dseed, rw, c0, p.drop_thresh) ? v.x * p.drop_scale : 0.f;
+          v.y = epi_keep(dseed, rw, c0 + 1, p.drop_thresh) ? v.y * p.drop_scale : 0.f;
+          v.z = epi_keep(dseed, rw, c0 + 2, p.drop_thresh) ? v.z * p.drop_scale : 0.f;
+          v.w = epi_keep(dseed, rw, c0 + 3, p.drop_thresh) ? v.w * p.drop_scale : 0.f;
         }
       }
       if (ok) st4e<C16>(Cb, lr * ldc + col4, v);

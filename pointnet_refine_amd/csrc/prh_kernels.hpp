@@ -433,7 +433,7 @@ __global__ void slab_reduce2_kernel(const float* __restrict__ slab, int S, int r
 // the ReLU backward of a Linear with a fused ReLU, and the operand maximum the backward GEMMs
 // need, in one pass (it was a compare, a select and a maximum pass)
 __global__ __launch_bounds__(256) void relu_mask_amax_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                             float* __restrict__ out, size_t n4,
+                                                             float* __restrict__ out, size_t n4, float scale,
                                                              float* __restrict__ part) {
   __shared__ float red[4];
   float m = 0.f;
@@ -441,7 +441,8 @@ __global__ __launch_bounds__(256) void relu_mask_amax_kernel(const float* __rest
     const float4 g = reinterpret_cast<const float4*>(dy)[i];
     const float4 v = reinterpret_cast<const float4*>(y)[i];
     float4 o;
-    o.x = v.x > 0.f ? g.x : 0.f; o.y = v.y > 0.f ? g.y : 0.f; o.z = v.z > 0.f ? g.z : 0.f; o.w = v.w > 0.f ? g.w : 0.f;
+    o.x = v.x > 0.f ? g.x * scale : 0.f; o.y = v.y > 0.f ? g.y * scale : 0.f;
+    o.z = v.z > 0.f ? g.z * scale : 0.f; o.w = v.w > 0.f ? g.w * scale : 0.f;
     reinterpret_cast<float4*>(out)[i] = o;
     m = fmaxf(m, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
   }

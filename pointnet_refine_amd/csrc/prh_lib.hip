@@ -1110,15 +1110,21 @@ int prh_linear_forward_ex(const float* x, long ldx, const float* w, const float*
 }
 int prh_linear_forward_full(const float* x, long ldx, const float* w, const float* b, const float* resid,
                             long ldres, float* y, int rows, int k, int n, int relu, const float* x_amax,
-                            const float* w_amax, void* workspace, size_t workspace_bytes, int device,
-                            void* stream) {
+                            const float* w_amax, float dropout_p, unsigned dropout_seed, void* workspace,
+                            size_t workspace_bytes, int device, void* stream) {
   if (!x || !w || !y || rows < 0 || k <= 0 || n <= 0 || (resid != nullptr && ldres < n))
     return fail(PRH_ERR_ARG, "linear_forward_full: bad argument");
+  if (!(dropout_p >= 0.f && dropout_p < 1.f)) return fail(PRH_ERR_ARG, "linear_forward_full: dropout_p must be in [0,1)");
   HIP_TRY(hipSetDevice(device));
   NTParams p; memset(&p, 0, sizeof(p));
   p.A = x; p.lda = ldx; p.W = w; p.ldw = k; p.C = y; p.ldc = n;
   p.M = rows; p.N = n; p.K = k; p.bias = b; p.flags = (relu ? F_RELU_OUT : 0) | (resid ? F_RESID : 0);
   p.E1 = resid; p.lde1 = ldres;
+  if (dropout_p > 0.f) {
+    p.flags |= F_DROPOUT;
+    p.drop_seed = dropout_seed; p.drop_thresh = (unsigned)((double)dropout_p * 4294967296.0);
+    p.drop_scale = 1.f / (1.f - dropout_p); p.seed_src = g_seed_src;
+  }
   p.amaxW = w_amax;
   if (workspace != nullptr && workspace_bytes >= s3_weight_bytes(n, k) + 256)
     p.wprep = (char*)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
@@ -1148,7 +1154,7 @@ int prh_operand_absmax(const float* x, long ld, long rows, int cols, float* out,
 // out = (y > 0 ? dy : 0), amax_out[0] = max|out|: ReLU backward of a Linear with a fused ReLU
 // (src/model.py:131,164 - linear1 + activation, reg_branches[i][0:2]); n = element count, % 4 == 0,
 // all three buffers contiguous and 16-B aligned.  Workspace: prh_operand_absmax_workspace_bytes().
-int prh_relu_mask_absmax(const float* dy, const float* y, float* out, long n, float* amax_out, void* workspace,
+int prh_relu_mask_absmax(const float* dy, const float* y, float* out, long n, float scale, float* amax_out, void* workspace,
                          size_t workspace_bytes, int device, void* stream) {
   if (!dy || !y || !out || !amax_out || n < 0 || (n & 3)) return fail(PRH_ERR_ARG, "relu_mask_absmax: bad argument");
   HIP_TRY(hipSetDevice(device));
@@ -1158,7 +1164,7 @@ int prh_relu_mask_absmax(const float* dy, const float* y, float* out, long n, fl
   hipStream_t st = (hipStream_t)stream;
   long blocks = cdiv(n / 4, 256L * 4);
   blocks = blocks < 1 ? 1 : (blocks > ABSMAX_MAX_BLOCKS ? ABSMAX_MAX_BLOCKS : blocks);
-  hipLaunchKernelGGL(relu_mask_amax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dy, y, out, (size_t)(n / 4), part);
+  hipLaunchKernelGGL(relu_mask_amax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dy, y, out, (size_t)(n / 4), scale, part);
   LAUNCH_CHECK();
   hipLaunchKernelGGL(absmax_final_kernel, dim3(1), dim3(256), 0, st, (const float*)part, (int)blocks, amax_out);
   LAUNCH_CHECK();

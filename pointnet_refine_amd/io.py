@@ -92,30 +92,31 @@ def refine_scene(model, pcd_points, raw_lines, num_line_points=32, num_context_p
         return np.zeros((0, num_line_points, 3)), np.zeros((0, num_line_points, 3))
     was_training = model.training
     model.eval()
-    from . import _lib as _L
+    from . import ops as _ops
     enc = getattr(model, "context_encoder", None)
     old_prec = getattr(enc, "inference_precision", None)
-    old_mode = _L.lib().prh_get_gemm_mode()
     if precision not in (None, "fp32", "fp16", "layers"):
         raise ValueError("refine_scene: precision must be None, 'fp32', 'fp16' or 'layers'")
+    import contextlib
+    # fp16: decoder GEMMs on one bf16 plane for the duration of the call (process-wide setting: the
+    # scope holds a lock and restores the previous mode on the way out, exception or not)
+    mode_scope = _ops.gemm_mode_scope("bf16") if precision == "fp16" else contextlib.nullcontext()
     try:
-        if precision is not None and enc is not None:
-            enc.inference_precision = None if precision == "layers" else precision
-        if precision == "fp16":
-            _L.check(_L.lib().prh_set_gemm_mode(4), "prh_set_gemm_mode")
-        ctx, noisy_c, centres, _ = build_contexts(cloud, raw_lines, num_line_points, num_context_points,
-                                                  crop_radius, decay_scale, seed)
-        outs = []
-        for s in range(0, ctx.shape[0], batch_lines):
-            outs.append(model(ctx[s:s + batch_lines], noisy_c[s:s + batch_lines])[-1])   # last layer, :139-141
-        offset = torch.cat(outs)
-        noisy = noisy_c + centres[:, None, :]
-        return (noisy + offset).cpu().numpy(), noisy.cpu().numpy()                         # :146
+        with mode_scope:
+            if precision is not None and enc is not None:
+                enc.inference_precision = None if precision == "layers" else precision
+            ctx, noisy_c, centres, _ = build_contexts(cloud, raw_lines, num_line_points, num_context_points,
+                                                      crop_radius, decay_scale, seed)
+            outs = []
+            for s in range(0, ctx.shape[0], batch_lines):
+                outs.append(model(ctx[s:s + batch_lines], noisy_c[s:s + batch_lines])[-1])   # last layer, :139-141
+            offset = torch.cat(outs)
+            noisy = noisy_c + centres[:, None, :]
+            return (noisy + offset).cpu().numpy(), noisy.cpu().numpy()                         # :146
     finally:
         model.train(was_training)
         if enc is not None:
             enc.inference_precision = old_prec
-        _L.lib().prh_set_gemm_mode(old_mode)
 
 
 class SceneSampleStream:

@@ -215,8 +215,11 @@ class DetrTransformerDecoderLayer(nn.Module):
         tgt = _add_norm(tgt, tgt2, self.norm2, self.dropout2, self.training)
         if self.activation is not F.relu:
             raise RuntimeError("pointnet_refine_amd: the FFN activation is ReLU (src/model.py:95), fused into the GEMM epilogue")
-        hid = ops.linear(tgt, self.linear1.weight, self.linear1.bias, None, True)      # ReLU rides on the epilogue
-        tgt2 = _lin(self.dropout(hid), self.linear2.weight, self.linear2.bias)
+        # linear2(dropout(relu(linear1(tgt)))) (src/model.py:131): ReLU AND the dropout ride on linear1's epilogue
+        pd = self.dropout.p if self.training else 0.0
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if pd > 0.0 else 0
+        hid = ops.linear(tgt, self.linear1.weight, self.linear1.bias, None, True, None, pd, seed)
+        tgt2 = _lin(hid, self.linear2.weight, self.linear2.bias)
         tgt = _add_norm(tgt, tgt2, self.norm3, self.dropout3, self.training)
         return tgt
 

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import threading
 from typing import List, Optional, Sequence
 
 import torch
@@ -45,6 +46,36 @@ def set_gemm_mode(mode) -> int:
     old = L.lib().prh_get_gemm_mode()
     L.check(L.lib().prh_set_gemm_mode(m), "prh_set_gemm_mode")
     return old
+
+
+_MODE_LOCK = threading.RLock()
+
+
+class gemm_mode_scope:
+    """with ops.gemm_mode_scope("bf16"): ... - the GEMM core family is ONE setting per process (the
+    library reads it in the forward and again in the backward, which runs on autograd's device thread,
+    so it cannot be thread-local); this scope takes a process-wide lock, switches the mode and puts the
+    previous one back on exit, exception or not.  Two threads that want different modes serialise here
+    instead of silently running each other's kernels."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        _MODE_LOCK.acquire()
+        try:
+            self.old = set_gemm_mode(self.mode)
+        except Exception:
+            _MODE_LOCK.release()
+            raise
+        return self
+
+    def __exit__(self, *exc):
+        try:
+            set_gemm_mode(self.old)
+        finally:
+            _MODE_LOCK.release()
+        return False
 
 
 def release_workspaces():
@@ -246,13 +277,20 @@ class LinearFn(torch.autograd.Function):
     """y = x W^T + b on the fp32 MFMA GEMM core (context_proj, src/model.py:147,194)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, x_amax=None, relu=False, resid=None):
+    def forward(ctx, x, w, b, x_amax=None, relu=False, resid=None, dropout_p=0.0, seed=0):
         """x_amax: optional 1-element device tensor >= max|x| (saves the read pass that places the
         operand for the split-fp16 core; e.g. the encoder's bound for its output).  relu: apply
         ReLU in the GEMM epilogue (the backward masks dy with y > 0).  resid: tensor of the output's
-        shape added in the epilogue, y = act(x W^T + b + resid)."""
+        shape added in the epilogue, y = act(x W^T + b + resid).  dropout_p > 0 (with relu): the output
+        leaves the epilogue dropped out, y = dropout(relu(.)), decided by a hash of (seed, row, column) -
+        the FFN hidden layer (src/model.py:131); the backward reads the mask off y."""
         ctx.w_sink, ctx.b_sink = _sink_view(w), _sink_view(b)
+        if dropout_p > 0.0 and not relu:
+            raise RuntimeError("pointnet_refine_amd.linear: epilogue dropout comes with the fused ReLU (the backward reads the mask off y > 0)")
+        ctx.drop_scale = 1.0 / (1.0 - dropout_p) if dropout_p > 0.0 else 1.0
         if x.dtype == torch.bfloat16:
+            if dropout_p > 0.0:
+                raise RuntimeError("pointnet_refine_amd.linear (bf16 input): no epilogue dropout")
             return LinearFn._forward_bf16(ctx, x, w, b, relu, resid)
         _req_gpu_f32(x, "input")
         _req_gpu_f32(w, "weight")
@@ -285,7 +323,8 @@ class LinearFn(torch.autograd.Function):
                 x_amax = operand_absmax(x2)
             w_amax = operand_absmax(w)
         L.check(L.lib().prh_linear_forward_full(_p(x2), k, _p(w), _p(b), _p(r2), n, _p(y), rows, k, n,
-                                                int(bool(relu)), _p(x_amax), _p(w_amax), _p(ws), ws.numel(),
+                                                int(bool(relu)), _p(x_amax), _p(w_amax), float(dropout_p),
+                                                int(seed) & 0xFFFFFFFF, _p(ws), ws.numel(),
                                                 x.device.index, _stream(x.device)),
                 "prh_linear_forward")
         ctx.has_resid = resid is not None
@@ -335,7 +374,7 @@ class LinearFn(torch.autograd.Function):
         ws = _ws(dev, L.lib().prh_linear_bf16_workspace_bytes(rows, k, n, 1))
         L.check(L.lib().prh_linear_backward_bf16(_p(x2), k, _p(w), _p(dy2), _p(dx), _p(dw), _p(db), rows, k, n, _p(ws),
                                                  ws.numel(), dev.index, _stream(dev)), "prh_linear_backward_bf16")
-        return (dx.reshape(ctx.xshape) if need_dx else None), _grad_ret(dw, tw), _grad_ret(db, tb), None, None, None
+        return (dx.reshape(ctx.xshape) if need_dx else None), _grad_ret(dw, tw), _grad_ret(db, tb), None, None, None, None, None
 
     @staticmethod
     def backward(ctx, dy):
@@ -361,7 +400,7 @@ class LinearFn(torch.autograd.Function):
             masked = torch.empty_like(dy2)
             dy_amax = torch.empty(1, dtype=torch.float32, device=dev)
             wsm = _ws(dev, L.lib().prh_operand_absmax_workspace_bytes())
-            L.check(L.lib().prh_relu_mask_absmax(_p(dy2), _p(y), _p(masked), dy2.numel(), _p(dy_amax), _p(wsm),
+            L.check(L.lib().prh_relu_mask_absmax(_p(dy2), _p(y), _p(masked), dy2.numel(), float(ctx.drop_scale), _p(dy_amax), _p(wsm),
                                                  wsm.numel(), dev.index, _stream(dev)), "prh_relu_mask_absmax")
             dy2 = masked
         need_dx, need_dw, need_db = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
@@ -377,11 +416,11 @@ class LinearFn(torch.autograd.Function):
         dres = None
         if ctx.has_resid and ctx.needs_input_grad[5]:
             dres = dy2.reshape(*ctx.xshape[:-1], n)      # (masked by the ReLU when there is one)
-        return (dx.reshape(ctx.xshape) if need_dx else None), _grad_ret(dw, tw), _grad_ret(db, tb), None, None, dres
+        return (dx.reshape(ctx.xshape) if need_dx else None), _grad_ret(dw, tw), _grad_ret(db, tb), None, None, dres, None, None
 
 
-def linear(x, w, b=None, x_amax=None, relu=False, resid=None):
-    return LinearFn.apply(x, w, b, x_amax, relu, resid)
+def linear(x, w, b=None, x_amax=None, relu=False, resid=None, dropout_p=0.0, seed=0):
+    return LinearFn.apply(x, w, b, x_amax, relu, resid, dropout_p, seed)
 
 
 class LinearOut16Fn(torch.autograd.Function):

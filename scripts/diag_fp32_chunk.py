@@ -39,6 +39,8 @@ batch = synthetic_batch(B, N, dev, seed=50)
 if PROC:
     from oracle import procedural as P
     batch = [t.to(dev) for t in P.synth_batch(B, N, 4, 32, seed=50)]
+SHIFT = float(os.environ.get("PRH_DIAG_SHIFT", "0"))      # move the target away from the predictions: no sign(0) ambiguity
+batch = [batch[0], batch[1], batch[2] + SHIFT]
 for mode in ((0,) if os.environ.get('PRH_DIAG_MODE0') else (0, 3)):
     lib.prh_set_gemm_mode(mode)
     res = {}
@@ -55,7 +57,11 @@ for mode in ((0,) if os.environ.get('PRH_DIAG_MODE0') else (0, 3)):
     for tag in ("chunk4", "chunk2"):
         o0, g0, names, sizes = res["mono"]
         o1, g1, _, _ = res[tag]
-        print(f"mode {mode} {tag}: out max|d| {float((o0 - o1).abs().max()):.3e}  all grads rel-L2 {float((g0 - g1).norm() / g0.norm()):.3e}")
+        tgt = batch[2].unsqueeze(0)
+        flips = int(((o0 - tgt).sign() != (o1 - tgt).sign()).sum())
+        near = int(((o0 - tgt).abs() < 1e-4).sum())
+        print(f"mode {mode} {tag}: out max|d| {float((o0 - o1).abs().max()):.3e}  all grads rel-L2 {float((g0 - g1).norm() / g0.norm()):.3e}"
+              f"  L1 sign flips between the two runs: {flips} of {o0.numel()} (|pred - target| < 1e-4: {near})")
         rows = []
         for n, (off, k) in zip(names, sizes):
             a, b = g0[off:off + k].double(), g1[off:off + k].double()

@@ -32,10 +32,12 @@ def test_two_ranks_product_model_through_train_step(tmp_path):
         assert p.returncode == 0, l[-3000:]
     res = json.load(open(out))
     assert res["n_params"] == 9695954
-    # chunked vs monolithic decoder: different GEMM shapes, fp32 rounding.  5.7e-6 on the default cores;
-    # with PRH_GEMM=fp32 the K/V projections of a 2-segment and a 6-segment launch take small-problem
-    # tilings with different k-split orders and the six iterative layers amplify that to 5e-4
-    assert res["grad_rel_l2"] < (1e-3 if os.environ.get("PRH_GEMM") == "fp32" else 1e-4), res
+    # chunked vs monolithic decoder: different GEMM tilings, i.e. fp32 re-association only - 1e-4 on every
+    # GEMM mode, PRH_GEMM=fp32 included.  What read 4.2e-4 there in round 2 is ONE ReLU unit whose
+    # pre-activation sits inside fp32 noise of zero and takes different sides in the two evaluations
+    # (profiles/r03_fp32_chunk_root_cause.txt); the worker counts the ReLU masks that differ, and only a
+    # counted flip widens the gate (~5e-4 per unit).
+    assert res["grad_rel_l2"] < (1e-4 if res["relu_flips"] == 0 else 2e-3 * res["relu_flips"]), res
     assert res["weights_equal"], res
     # per-rank statistics, no SyncBN: the ranks' running means differ by their local batches
     # only, not by the +5 rank 1 started with (overwritten by the rank-0 broadcast)

@@ -4,7 +4,7 @@ import ctypes as C
 import pytest
 import torch
 
-from conftest import maxdiff
+from conftest import maxdiff, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -30,7 +30,11 @@ def lib(request):
                                    (512, 128, 64), (1031, 1984, 1024),
                                    # small-problem cores (prh_small.hpp): 32x32 / 32x64 / 64x64 tiles
                                    (1024, 256, 256), (1024, 1024, 256), (1024, 256, 1024), (4096, 256, 256),
-                                   (1000, 100, 128), (33, 256, 64), (1, 8, 64), (3000, 252, 192)])
+                                   (1000, 100, 128), (33, 256, 64), (1, 8, 64), (3000, 252, 192),
+                                   # the decoder's launches at 2 / 4 / 6 segments of 160 points (tests/test_dist_gpu.py:
+                                   # K/V projections and query-side Linears of a chunked and a monolithic step)
+                                   (320, 1536, 256), (640, 1536, 256), (960, 1536, 256), (64, 768, 256),
+                                   (128, 512, 256), (192, 256, 1024), (192, 1024, 256)])
 def test_gemm_nt(lib, m, n, k):
     g = torch.Generator(device="cuda").manual_seed(m * 7 + n * 3 + k)
     a = torch.randn(m, k, device="cuda", generator=g)
@@ -53,7 +57,9 @@ def test_gemm_nt(lib, m, n, k):
                                      (20000, 1024, 1984),
                                      # small wgrad core: rows and both widths multiples of 64
                                      (1024, 256, 256), (1024, 1024, 256), (64, 64, 64), (4096, 128, 1024),
-                                     (1088, 256, 192), (6144, 128, 64), (2048, 96, 32)])
+                                     (1088, 256, 192), (6144, 128, 64), (2048, 96, 32),
+                                     # the K / V projection wgrads of a 2 / 4 / 6-segment decoder chunk
+                                     (320, 1536, 256), (640, 1536, 256), (960, 1536, 256), (192, 1024, 256)])
 def test_gemm_tn(lib, p, mo, ni):
     g = torch.Generator(device="cuda").manual_seed(p + mo + ni)
     a = torch.randn(p, mo, device="cuda", generator=g)
@@ -236,3 +242,39 @@ def test_small_linear_forward_backward(rows, k, n, relu, resid):
     assert maxdiff(b.grad, bd.grad) < 2e-5 * rows ** 0.5
     if resid:
         assert maxdiff(r.grad, rd.grad) < 1e-6
+
+
+@pytest.mark.parametrize("rows,mode", [(64, 3), (1024, 3), (65536, 3), (65536, 0), (65536, 4)])
+def test_linear_relu_dropout_epilogue(rows, mode):
+    """FFN hidden layer (src/model.py:131): y = dropout(relu(x W1^T + b1)) leaves the GEMM epilogue of
+    every core family (small-problem core, 128 x 128 fp32 core, split-fp16 / bf16 NT cores) already
+    dropped out; the keep decision is the (seed, row, column) hash ops.layernorm_keep_mask re-creates,
+    and the backward masks with it through y > 0."""
+    from pointnet_refine_amd import _lib, ops
+    lib = _lib.lib()
+    old = lib.prh_get_gemm_mode()
+    lib.prh_set_gemm_mode(mode)
+    try:
+        torch.manual_seed(rows + mode)
+        k, n, p, seed = 256, 1024, 0.1, 12345
+        x = torch.randn(rows, k, device="cuda", requires_grad=True)
+        w = (torch.randn(n, k, device="cuda") / 16).requires_grad_(True)
+        b = torch.randn(n, device="cuda", requires_grad=True)
+        y = ops.linear(x, w, b, None, True, None, p, seed)
+        keep = ops.layernorm_keep_mask(rows, n, p, seed, device="cuda")
+        up = torch.randn_like(y)
+        (y * up).sum().backward()
+        xd, wd, bd = (t.detach().double() for t in (x, w, b))
+        pre = xd @ wd.t() + bd
+        ref = torch.relu(pre) * keep / (1.0 - p)
+        tol = 5e-2 if mode == 4 else 1e-5
+        # same mask: dropped elements are exact zeros, kept ones follow the reference (ReLU ties aside: a
+        # pre-activation inside fp32 noise of 0 may round to either side - ~5 of the 67 M elements at 65536 rows)
+        assert float(((y == 0) != (ref == 0)).float().mean()) < (2e-3 if mode == 4 else 1e-6)
+        assert rel_l2(ref, y) < tol
+        assert abs(float(keep.float().mean()) - (1.0 - p)) < 5e-3
+        # backward through the mask the FORWARD produced (y > 0), so that tie flips do not count
+        g = up.double() * (y.detach() > 0) / (1.0 - p)
+        assert rel_l2(g @ wd, x.grad) < tol and rel_l2(g.t() @ xd, w.grad) < tol and rel_l2(g.sum(0), b.grad) < tol
+    finally:
+        lib.prh_set_gemm_mode(old)
