@@ -70,6 +70,11 @@ struct NTParams {
   char* wprep;                   // scratch for the split weight image (null: fp32 MFMA core)
   const float* amaxA;            // fp16-plane cores: largest |pro(A)| (device; null: the launch
   const float* amaxW;            //   measures it) and largest |W| (set by the launch)
+  int mask_col0;                      // EPI_DGRAD (vector epilogue): F_MASK / F_STATS apply to columns >= mask_col0 only
+                                      //   (a multiple of 64).  The fusion conv's dgrad writes the gradient of all five
+                                      //   conv blocks; blocks 1..4 are only PARTIAL there - the conv dgrad that later
+                                      //   completes a block accumulates into it and masks the sum (mask (a + b) =
+                                      //   mask a + mask b) and takes its statistics - so their z need not be read here
   unsigned drop_seed, drop_thresh;    // F_DROPOUT: host seed, p * 2^32
   float drop_scale;                   //   1 / (1 - p)
   const unsigned* seed_src;           //   optional device word mixed into the seed (graph replays)
@@ -452,10 +457,12 @@ __device__ __forceinline__ void nt_epilogue_vec(ACC& acc, const NTParams& p, int
   // statistics straight from the accumulators (column on the lane): sum, then centred M2
   if (EPI == EPI_BIAS_STATS) epi_col_stats(acc, p, cbase, mrows, rb, lane, biasp);
 
-  const bool mask = (p.flags & F_MASK) != 0, accum = (p.flags & F_ACCUM) != 0;
+  const bool tile_masked = EPI != EPI_DGRAD || cbase >= p.mask_col0;      // wave-uniform (64-column wave tiles)
+  const bool mask = (p.flags & F_MASK) != 0 && tile_masked, accum = (p.flags & F_ACCUM) != 0;
+  const bool stats = EPI == EPI_DGRAD && (p.flags & F_STATS) != 0 && tile_masked;
   const bool resid = EPI == EPI_BIAS && (p.flags & F_RESID) != 0;
   const unsigned dseed = (EPI == EPI_BIAS && (p.flags & F_DROPOUT) != 0) ? epi_seed(p) : 0u;
-  const bool need_z = (EPI == EPI_DGRAD && (mask || (p.flags & F_STATS) != 0)) || EPI == EPI_GATE || resid;
+  const bool need_z = (EPI == EPI_DGRAD && (mask || stats)) || EPI == EPI_GATE || resid;
   float4 s1 = zero4(), s2 = zero4();
   const bool pool = EPI == EPI_GATE && (p.flags & F_POOL) != 0;
   float pmx[4] = {-1.f, -1.f, -1.f, -1.f}, psm[4] = {0.f, 0.f, 0.f, 0.f};     // outputs are >= 0
@@ -595,7 +602,7 @@ __device__ __forceinline__ void nt_epilogue_vec(ACC& acc, const NTParams& p, int
       *reinterpret_cast<int4*>(p.ws_c + (size_t)rb * p.N + col4) = make_int4(pix[0], pix[1], pix[2], pix[3]);
     }
   }
-  if (EPI == EPI_DGRAD && (p.flags & F_STATS) != 0) {
+  if (stats) {
     // column sums: reduce over the 4 row groups (lane bits 4,5)
     s1.x += __shfl_xor(s1.x, 16); s1.y += __shfl_xor(s1.y, 16); s1.z += __shfl_xor(s1.z, 16); s1.w += __shfl_xor(s1.w, 16);
     s2.x += __shfl_xor(s2.x, 16); s2.y += __shfl_xor(s2.y, 16); s2.z += __shfl_xor(s2.z, 16); s2.w += __shfl_xor(s2.w, 16);

@@ -221,3 +221,41 @@ def test_train_step_bf16_mode_learns(bf16_mode):
     losses = [float(step(ctx, noisy, target)) for _ in range(12)]
     assert all(np.isfinite(losses)), losses
     assert min(losses[-3:]) < 0.8 * losses[0], losses
+
+
+def test_model_bf16_every_gradient_vs_fp64_oracle(bf16_mode):
+    """absolute gates, on WHOLE tensors, against the oracle in fp64 on the G2 inputs
+    (B=8, N=256, train mode, dropout off) - not "no worse than the reference under autocast" on 64-entry
+    heads.  Measured on this mode (r03): out rel-L2 2.4e-2; per-tensor gradient rel-L2 median 2.9e-2,
+    90th percentile 6.6e-2, worst 0.14 (a decoder in_proj_weight); the gates sit ~1.5x above that.
+    (2,048 context points per BatchNorm statistic here; at the benchmark's 4.19 M points the worst tensor
+    reads 1.7e-2, bench.py's at_init gate.)"""
+    import re
+    from oracle import linerefine_oracle as O
+    sd = P.linerefine_state_dict(0)
+    m = _model(sd).train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        if isinstance(mod, torch.nn.MultiheadAttention):
+            mod.dropout = 0.0
+    ctx, noisy, target = P.synth_batch(8, 256, 4, 32, seed=1234)
+    out = m(ctx.cuda(), noisy.cuda())
+    loss = sum(torch.nn.functional.l1_loss(out[l], target.cuda()) for l in range(6)) / 6
+    loss.backward()
+    p = O.as_params(sd, dtype=torch.float64, requires_grad=True)
+    o64 = O.linerefine_forward(p, ctx.double(), noisy.double(), training=True, new_stats={})
+    O.deep_supervision_l1(o64, target.double()).backward()
+    rels = {}
+    for k, v in m.named_parameters():
+        if re.search(r"(conv\\d\\.bias|fusion\\.0\\.bias|point_mlp\\.[036]\\.bias)$", k):
+            continue                                  # analytically zero in front of a train-mode BatchNorm
+        rels[k] = rel_l2(p[k].grad, v.grad)
+    vals = sorted(rels.values())
+    worst = max(rels, key=rels.get)
+    print(f"bf16 mode vs fp64 oracle (G2 inputs): out rel-L2 {rel_l2(o64, out):.3e}; per-tensor gradient rel-L2 median "
+          f"{vals[len(vals) // 2]:.3e}, p90 {vals[int(len(vals) * 0.9)]:.3e}, worst {rels[worst]:.3e} ({worst})")
+    assert rel_l2(o64, out) < 4e-2
+    assert vals[len(vals) // 2] < 4.5e-2
+    assert vals[int(len(vals) * 0.9)] < 1.0e-1
+    assert rels[worst] < 2.2e-1, (worst, rels[worst])
