@@ -42,7 +42,7 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0     # dense v_mfma_f32_{32x32x16,16x16x32}_{bf16,
 HBM_PEAK_GBS = 8000.0
 GEMM_MODES = {"fp32": 0, "split": 1, "bf16op": 2, "split16": 3, "bf16": 4}
 DEFAULT_GEMM = "split16"
-PMC_TRAFFIC_FILES = {3: "r02x_pmc_traffic_B4096_split16.json", 4: "r02x_pmc_traffic_B4096_bf16.json"}   # gemm mode -> committed PMC pass
+PMC_TRAFFIC_FILES = {3: "r03m_pmc_traffic_B4096_split16.json", 4: "r03m_pmc_traffic_B4096_bf16.json"}   # gemm mode -> committed PMC pass
 # MFMA products issued per algorithmic MAC and what the peak is quoted on, per gemm mode
 MODE_INFO = {
     0: (1, FP32_MFMA_PEAK_TFLOPS, "157.3 TF fp32 MFMA (v_mfma_f32_32x32x2_f32)",

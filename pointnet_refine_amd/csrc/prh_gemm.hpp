@@ -615,6 +615,248 @@ __device__ __forceinline__ void nt_epilogue_vec(ACC& acc, const NTParams& p, int
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// [r03] Direct epilogue for TRANSPOSED 16x16 MFMA blocks.  With the operands of v_mfma_f32_16x16x32_f16
+// swapped (weights as the A operand, activations as B) the block comes out as D'[n][m]: a lane holds
+// FOUR CONSECUTIVE OUTPUT COLUMNS of one row,
+//     acc[i][j][r] = C[row = 16 i + (lane & 15)][col = 16 j + 4 (lane >> 4) + r],
+// i.e. 16 contiguous bytes of the row-major fp32 output - the layout the stores (and every epilogue
+// operand read: z for the ReLU mask, the old gradient, the residual, zf and the gate) want anyway.  No
+// LDS round trip: the wave-private scratch transposes of nt_epilogue_vec (32 ds_write_b32 + 8
+// ds_read_b128 per 32-row block) are gone, and with them a third of the epilogue's instructions; a tile
+// of 64 columns is walked as two halves of 32 so that the two 64-byte pieces a row's four lanes write
+// per block pair complete one 128-byte line back to back.  Column statistics (a lane's 4 columns x the
+// 16 rows of its lane group) are reduced over the 16 lanes by DPP-friendly xor shuffles (1, 2, 4, 8).
+// Same arithmetic and the same partial-array formats as nt_epilogue_vec.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 shfl_xor4(float4 v, int o) {
+  return make_float4(__shfl_xor(v.x, o), __shfl_xor(v.y, o), __shfl_xor(v.z, o), __shfl_xor(v.w, o));
+}
+__device__ __forceinline__ float4 red16_add(float4 v) {
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) { const float4 t = shfl_xor4(v, o); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+  return v;
+}
+__device__ __forceinline__ float4 red16_max(float4 v) {
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) { const float4 t = shfl_xor4(v, o); v.x = fmaxf(v.x, t.x); v.y = fmaxf(v.y, t.y); v.z = fmaxf(v.z, t.z); v.w = fmaxf(v.w, t.w); }
+  return v;
+}
+__device__ __forceinline__ float4 red16_min(float4 v) {
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) { const float4 t = shfl_xor4(v, o); v.x = fminf(v.x, t.x); v.y = fminf(v.y, t.y); v.z = fminf(v.z, t.z); v.w = fminf(v.w, t.w); }
+  return v;
+}
+
+// per-column sum and centred M2 (and optionally max / min) of acc + bias over the wave tile's valid rows
+__device__ __forceinline__ void epi_col_stats_t(const f32x4 (&acc)[8][4], const NTParams& p, int cbase, int mrows, int rb,
+                                                int lane, const float* biasp) {
+  const int l15 = lane & 15, q = lane >> 4;
+  const int nrows = mrows < 0 ? 0 : (mrows > 128 ? 128 : mrows);
+  const float inv_n = nrows > 0 ? 1.f / (float)nrows : 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col4 = cbase + j * 16 + 4 * q;
+    const bool cok = col4 < p.N;
+    const float4 b4 = (biasp != nullptr && cok) ? ldg4(biasp + col4) : zero4();
+    float4 s = zero4();
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i * 16 + l15 < mrows) { s.x += acc[i][j][0] + b4.x; s.y += acc[i][j][1] + b4.y; s.z += acc[i][j][2] + b4.z; s.w += acc[i][j][3] + b4.w; }
+    s = red16_add(s);
+    const float4 mean = make_float4(s.x * inv_n, s.y * inv_n, s.z * inv_n, s.w * inv_n);
+    float4 m2 = zero4();
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i * 16 + l15 < mrows) {
+        const float dx = acc[i][j][0] + b4.x - mean.x, dy = acc[i][j][1] + b4.y - mean.y;
+        const float dz = acc[i][j][2] + b4.z - mean.z, dw = acc[i][j][3] + b4.w - mean.w;
+        m2.x = fmaf(dx, dx, m2.x); m2.y = fmaf(dy, dy, m2.y); m2.z = fmaf(dz, dz, m2.z); m2.w = fmaf(dw, dw, m2.w);
+      }
+    m2 = red16_add(m2);
+    if (l15 == 0 && cok) {
+      *reinterpret_cast<float4*>(p.ws_a + (size_t)rb * p.N + col4) = s;
+      *reinterpret_cast<float4*>(p.ws_b + (size_t)rb * p.N + col4) = m2;
+    }
+    if (p.ws_c != nullptr) {
+      float4 mx = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f), mn = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (i * 16 + l15 < mrows) {
+          const float a0 = acc[i][j][0] + b4.x, a1 = acc[i][j][1] + b4.y, a2 = acc[i][j][2] + b4.z, a3 = acc[i][j][3] + b4.w;
+          mx.x = fmaxf(mx.x, a0); mx.y = fmaxf(mx.y, a1); mx.z = fmaxf(mx.z, a2); mx.w = fmaxf(mx.w, a3);
+          mn.x = fminf(mn.x, a0); mn.y = fminf(mn.y, a1); mn.z = fminf(mn.z, a2); mn.w = fminf(mn.w, a3);
+        }
+      mx = red16_max(mx); mn = red16_min(mn);
+      if (l15 == 0 && cok) {
+        *reinterpret_cast<float4*>(p.ws_c + (size_t)rb * p.N + col4) = mx;
+        *reinterpret_cast<float4*>(p.ws_d + (size_t)rb * p.N + col4) = mn;
+      }
+    }
+  }
+}
+
+template <int EPI>
+__device__ __forceinline__ void nt_epilogue_t(f32x4 (&acc)[8][4], const NTParams& p, int rbase_, int cbase, int rb, int lane) {
+  const int rbase = __builtin_amdgcn_readfirstlane(rbase_);
+  const int l15 = lane & 15, q = lane >> 4;
+  const int mrows = p.M - rbase;
+  const int ldc = (int)p.ldc, lde1 = (int)p.lde1, ldc2 = (int)p.ldc2;
+  const bool rowvec = EPI == EPI_DGRAD && (p.flags & F_E1_ROWVEC) != 0;
+  float* __restrict__ Cb = p.C + (size_t)rbase * p.ldc;
+  const float* __restrict__ Eb = p.E1 != nullptr ? p.E1 + (size_t)rbase * p.lde1 : nullptr;
+  float* __restrict__ C2b = (EPI == EPI_GATE && p.C2 != nullptr) ? p.C2 + (size_t)rbase * p.ldc2 : nullptr;
+  // load bases: a wave tile entirely below the matrix reads (and discards) row 0 instead
+  const float* __restrict__ Cl = mrows > 0 ? Cb : p.C;
+  const float* __restrict__ El = mrows > 0 ? Eb : p.E1;
+
+  if (EPI == EPI_BIAS_STATS) epi_col_stats_t(acc, p, cbase, mrows, rb, lane, p.bias);
+
+  const bool tile_masked = EPI != EPI_DGRAD || cbase >= p.mask_col0;      // wave-uniform
+  const bool mask = (p.flags & F_MASK) != 0 && tile_masked, accum = (p.flags & F_ACCUM) != 0;
+  const bool stats = EPI == EPI_DGRAD && (p.flags & F_STATS) != 0 && tile_masked;
+  const bool resid = EPI == EPI_BIAS && (p.flags & F_RESID) != 0;
+  const bool need_z = (EPI == EPI_DGRAD && (mask || stats)) || EPI == EPI_GATE || resid;
+  const bool acc_old = EPI == EPI_DGRAD && accum;
+  const bool pool = EPI == EPI_GATE && (p.flags & F_POOL) != 0;
+  const unsigned dseed = (EPI == EPI_BIAS && (p.flags & F_DROPOUT) != 0) ? epi_seed(p) : 0u;
+
+#pragma unroll
+  for (int jh = 0; jh < 2; ++jh) {
+    int col4[2]; bool cok[2];
+    float4 bias4[2], es4[2], et4[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      col4[jj] = cbase + (2 * jh + jj) * 16 + 4 * q;
+      cok[jj] = col4[jj] < p.N;
+      bias4[jj] = (p.bias != nullptr && cok[jj]) ? ldg4(p.bias + col4[jj]) : zero4();
+      es4[jj] = zero4(); et4[jj] = zero4();
+      if (cok[jj] && ((EPI == EPI_DGRAD && mask) || EPI == EPI_GATE)) { es4[jj] = ldg4(p.es + col4[jj]); et4[jj] = ldg4(p.et + col4[jj]); }
+    }
+    float4 s1[2] = {zero4(), zero4()}, s2[2] = {zero4(), zero4()};
+    float pmx[2][4], psm[2][4]; int pix[2][4];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { pmx[jj][e] = -1.f; psm[jj][e] = 0.f; pix[jj][e] = 0; }      // outputs are >= 0
+
+    // epilogue operands of row block i + 1 are requested before block i is processed (rows and columns
+    // clamped into the valid range, branch-free; only the stores are predicated)
+    float4 zz[2][2], oo[2][2];
+    auto issue = [&](int i, float4 (&z)[2], float4 (&o)[2]) {
+      const float* Em = El; const float* Cm = Cl;
+      asm volatile("" : "+s"(Em), "+s"(Cm) : : "memory");
+      int r = i * 16 + l15;
+      r = r < mrows ? r : mrows - 1;
+      r = r < 0 ? 0 : r;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int cc = cok[jj] ? col4[jj] : (p.N - 4);
+        z[jj] = zero4(); o[jj] = zero4();
+        if (need_z) {
+          if (rowvec) { const float sv = Em[(size_t)r * lde1]; z[jj] = make_float4(sv, sv, sv, sv); }
+          else z[jj] = ldg4(Em + (size_t)r * lde1 + cc);
+        }
+        if (acc_old) o[jj] = ldg4(Cm + (size_t)r * ldc + cc);
+      }
+    };
+    issue(0, zz[0], oo[0]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (i + 1 < 8) issue(i + 1, zz[(i + 1) & 1], oo[(i + 1) & 1]);
+      const int lr = i * 16 + l15;
+      const bool rok = lr < mrows;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int j = 2 * jh + jj;
+        const bool ok = rok && cok[jj];
+        float4 v = make_float4(acc[i][j][0] + bias4[jj].x, acc[i][j][1] + bias4[jj].y, acc[i][j][2] + bias4[jj].z,
+                               acc[i][j][3] + bias4[jj].w);
+        const float4 z = zz[i & 1][jj];
+        const float4 o = oo[i & 1][jj];
+        if (EPI == EPI_DGRAD) {
+          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+          if (mask) {
+            v.x = fmaf(z.x, es4[jj].x, et4[jj].x) > 0.f ? v.x : 0.f;
+            v.y = fmaf(z.y, es4[jj].y, et4[jj].y) > 0.f ? v.y : 0.f;
+            v.z = fmaf(z.z, es4[jj].z, et4[jj].z) > 0.f ? v.z : 0.f;
+            v.w = fmaf(z.w, es4[jj].w, et4[jj].w) > 0.f ? v.w : 0.f;
+          }
+          const float4 qv = ok ? v : zero4();
+          s1[jj].x += qv.x; s1[jj].y += qv.y; s1[jj].z += qv.z; s1[jj].w += qv.w;
+          s2[jj].x = fmaf(qv.x, z.x, s2[jj].x); s2[jj].y = fmaf(qv.y, z.y, s2[jj].y);
+          s2[jj].z = fmaf(qv.z, z.z, s2[jj].z); s2[jj].w = fmaf(qv.w, z.w, s2[jj].w);
+        } else if (EPI == EPI_GATE) {
+          // F = relu(zf*s+t) * m,  m = 0.5 + 0.5*sigmoid(acc + b)     (src/model.py:51,54-55)
+          float4 m;
+          m.x = 0.5f + 0.5f / (1.f + __expf(-v.x)); m.y = 0.5f + 0.5f / (1.f + __expf(-v.y));
+          m.z = 0.5f + 0.5f / (1.f + __expf(-v.z)); m.w = 0.5f + 0.5f / (1.f + __expf(-v.w));
+          v.x = fmaxf(fmaf(z.x, es4[jj].x, et4[jj].x), 0.f) * m.x; v.y = fmaxf(fmaf(z.y, es4[jj].y, et4[jj].y), 0.f) * m.y;
+          v.z = fmaxf(fmaf(z.z, es4[jj].z, et4[jj].z), 0.f) * m.z; v.w = fmaxf(fmaf(z.w, es4[jj].w, et4[jj].w), 0.f) * m.w;
+          if (ok && (p.flags & F_STORE_GATE) != 0) *reinterpret_cast<float4*>(C2b + (size_t)lr * ldc2 + col4[jj]) = m;
+          if (pool && ok) {      // a lane walks its rows in increasing order: strict > keeps the first maximum
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (vv[e] > pmx[jj][e]) { pmx[jj][e] = vv[e]; pix[jj][e] = lr; }
+              psm[jj][e] += vv[e];
+            }
+          }
+        } else {
+          if (resid) { v.x += z.x; v.y += z.y; v.z += z.z; v.w += z.w; }
+          if ((p.flags & F_RELU_OUT) != 0) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+          }
+          if (EPI == EPI_BIAS && (p.flags & F_DROPOUT) != 0) {
+            const unsigned rw = (unsigned)(rbase + lr), c0 = (unsigned)col4[jj];
+            v.x = epi_keep(dseed, rw, c0, p.drop_thresh) ? v.x * p.drop_scale : 0.f;
+            v.y = epi_keep(dseed, rw, c0 + 1, p.drop_thresh) ? v.y * p.drop_scale : 0.f;
+            v.z = epi_keep(dseed, rw, c0 + 2, p.drop_thresh) ? v.z * p.drop_scale : 0.f;
+            v.w = epi_keep(dseed, rw, c0 + 3, p.drop_thresh) ? v.w * p.drop_scale : 0.f;
+          }
+        }
+        if (ok) *reinterpret_cast<float4*>(Cb + (size_t)lr * ldc + col4[jj]) = v;
+      }
+      // keep the running column sums here (left alone, the compiler sinks the accumulation steps into the
+      // `stats` branch below and carries every v and z there: spills, as in nt_epilogue_vec)
+      if (EPI == EPI_DGRAD)
+        asm volatile("" : "+v"(s1[0].x), "+v"(s1[0].y), "+v"(s1[0].z), "+v"(s1[0].w), "+v"(s1[1].x), "+v"(s1[1].y), "+v"(s1[1].z),
+                     "+v"(s1[1].w), "+v"(s2[0].x), "+v"(s2[0].y), "+v"(s2[0].z), "+v"(s2[0].w), "+v"(s2[1].x), "+v"(s2[1].y),
+                     "+v"(s2[1].z), "+v"(s2[1].w));
+    }
+    if (pool) {
+      // combine the 16 lanes of a group (rows 16 i + l15): larger value wins, ties go to the smaller row
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) {
+            const float ov = __shfl_xor(pmx[jj][e], o);
+            const int oi = __shfl_xor(pix[jj][e], o);
+            psm[jj][e] += __shfl_xor(psm[jj][e], o);
+            if (ov > pmx[jj][e] || (ov == pmx[jj][e] && oi < pix[jj][e])) { pmx[jj][e] = ov; pix[jj][e] = oi; }
+          }
+        if (l15 == 0 && cok[jj]) {
+          *reinterpret_cast<float4*>(p.ws_a + (size_t)rb * p.N + col4[jj]) = make_float4(pmx[jj][0], pmx[jj][1], pmx[jj][2], pmx[jj][3]);
+          *reinterpret_cast<float4*>(p.ws_b + (size_t)rb * p.N + col4[jj]) = make_float4(psm[jj][0], psm[jj][1], psm[jj][2], psm[jj][3]);
+          *reinterpret_cast<int4*>(p.ws_c + (size_t)rb * p.N + col4[jj]) = make_int4(pix[jj][0], pix[jj][1], pix[jj][2], pix[jj][3]);
+        }
+      }
+    }
+    if (stats) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const float4 a = red16_add(s1[jj]), b = red16_add(s2[jj]);
+        if (l15 == 0 && cok[jj]) {
+          *reinterpret_cast<float4*>(p.ws_a + (size_t)rb * p.N + col4[jj]) = a;
+          *reinterpret_cast<float4*>(p.ws_b + (size_t)rb * p.N + col4[jj]) = b;
+        }
+      }
+    }
+  }
+}
+
 // NARROW: N <= 64 (one column tile).  The 2x2 wave grid then covers 128 x 64 with 64 x 32 wave
 // tiles instead of spending half of every MFMA on columns that do not exist (the intensity
 // gate's dgrad, K=1024 N=64, ran at 80 % of the fp32 matrix peak with half of it wasted).

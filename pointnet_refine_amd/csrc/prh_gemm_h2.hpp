@@ -23,6 +23,16 @@
 
 namespace prh {
 
+#ifndef PRH_H2_DIRECT_EPILOGUE
+#define PRH_H2_DIRECT_EPILOGUE 0
+#endif
+// [r03] 1: transposed MFMA blocks + stores straight from registers (nt_epilogue_t, prh_gemm.hpp).  Built,
+// parity-green on every GEMM / encoder / model test, measured on one box against the LDS-transposing vector
+// epilogue (scripts/ab_epilogue.sh, B=4096): fusion dgrad 49.2 vs 46.5 ms, fusion fwd 40.9 vs 40.4, conv5 fwd
+// 14.6 vs 13.9, gate 11.9 vs 8.7, K/V projections 5.86 vs 5.65, step 453.5 vs 443.1 ms - SLOWER everywhere: a
+// store or operand read of 16 rows x 64 B per instruction costs more than the scratch round trip that turns
+// it into 4 rows x 256 B.  Kept as a compile-time option for that comparison; the default stays 0.
+constexpr bool H2_DIRECT_EPILOGUE = PRH_H2_DIRECT_EPILOGUE != 0;
 constexpr int H2_BK = 32;
 constexpr int H2_PLANE = 256 * H2_BK * 2;         // one [256][32] fp16 plane = 16 KB
 constexpr int H2_OPER = 2 * H2_PLANE;             // two planes = 32 KB
@@ -76,7 +86,10 @@ __global__ __launch_bounds__(256) void prep_weights_h2_kernel(const float* __res
 // (A wgrad core on this loop - 32 rows per k-tile, 16 scalar loads per operand and thread - was
 // built and measured: 13.3 vs 12.9 ms on the fusion wgrad.  The TN core is bound by its
 // column-wise staging, not by the matrix pipe's clock, so it stays on the 32x32x16 loop.)
-template <int I0 = 0, int I1 = 8>
+// [r03] TR: the two operands of every MFMA are swapped (weights as the A operand), so a block comes out
+// transposed - acc[i][j][r] = C[row 16 i + (lane & 15)][col 16 j + 4 (lane >> 4) + r] - the layout
+// nt_epilogue_t stores straight from registers (prh_gemm.hpp).  Same fragments, same LDS reads, same sums.
+template <int I0 = 0, int I1 = 8, bool TR = false>
 __device__ __forceinline__ void h2_compute(f32x4 (&acc)[8][4], const char* st, int wm, int wn, int l15,
                                            int kc) {
   f16x8 wh[4], wl[4];
@@ -93,9 +106,15 @@ __device__ __forceinline__ void h2_compute(f32x4 (&acc)[8][4], const char* st, i
     const f16x8 al = *reinterpret_cast<const f16x8*>(q + H2_PLANE);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[j], acc[i][j], 0, 0, 0);
-      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[j], acc[i][j], 0, 0, 0);
-      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[j], acc[i][j], 0, 0, 0);
+      if (TR) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], al, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], ah, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], ah, acc[i][j], 0, 0, 0);
+      } else {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[j], acc[i][j], 0, 0, 0);
+      }
     }
   }
 }
@@ -204,7 +223,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_h2_kernel(const NTParams p,
     __builtin_amdgcn_sched_barrier(0);   // DMA strictly before the A loads (vmcnt is in order)
     if (!TAIL) load_tile(kt + 2, ra[CS ^ 1]);
     __builtin_amdgcn_sched_barrier(0);
-    h2_compute(acc, cur, wm, wn, l15, kc);
+    h2_compute<0, 8, H2_DIRECT_EPILOGUE>(acc, cur, wm, wn, l15, kc);
     store_tile(kt + 1, nxt, ra[CS]);
     // interleave the conversion (~130 VALU) with the 96 MFMAs
 #pragma unroll
@@ -248,8 +267,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_h2_kernel(const NTParams p,
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[i][j][r] *= unscale;
-  nt_epilogue_vec<EPI, 4>(acc, p, m0 + wm, n0 + wn, tile_m * 2 + (wave >> 2), lane,
-                          reinterpret_cast<float*>(smem) + wave * (32 * EPI_LDW));
+  if (H2_DIRECT_EPILOGUE)
+    nt_epilogue_t<EPI>(acc, p, m0 + wm, n0 + wn, tile_m * 2 + (wave >> 2), lane);
+  else
+    nt_epilogue_vec<EPI, 4>(acc, p, m0 + wm, n0 + wn, tile_m * 2 + (wave >> 2), lane,
+                            reinterpret_cast<float*>(smem) + wave * (32 * EPI_LDW));
 }
 
 // ---------------------------------------------------------------------------------------
