@@ -162,6 +162,9 @@ inline int attn_prec() {
   return g_attn_bf16 ? 1 : 0;
 }
 bool g_pool_fused = [] { const char* e = getenv("PRH_POOL_FUSED"); return !(e && strcmp(e, "0") == 0); }();
+// PRH_DGRAD_PARTIAL=1: the fusion dgrad skips the ReLU mask / statistics (and the z read) of the four conv blocks a
+// later dgrad completes (NTParams.mask_col0).  Off by default: see DESIGN.md section 7 (L2 sharing of the A tile)
+bool g_dgrad_partial = [] { const char* e = getenv("PRH_DGRAD_PARTIAL"); return e && strcmp(e, "1") == 0; }();
 inline const char* core_tag() { return core_mode() == 2 ? "b1" : (core_mode() == 3 ? "h2" : "s3"); }
 
 // largest |pro(A)| over [rows, cols] into *slot; part: ABSMAX_MAX_BLOCKS floats of scratch
@@ -1615,7 +1618,7 @@ int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B,
     p.flags = F_MASK | F_STATS;
     // blocks 1..4 are partial here and are masked (and measured) by the conv dgrad that completes them:
     // the epilogue reads z and takes sums for layer 5's block only (vector epilogue; 64-column granularity)
-    if ((d.off[4] & 63) == 0) p.mask_col0 = d.off[4];
+    if (g_dgrad_partial && (d.off[4] & 63) == 0) p.mask_col0 = d.off[4];
     if (matf) TRY((launch_nt<PRO_NONE, EPI_DGRAD>(p, st, &si5)));
     else TRY((launch_nt<PRO_BNBWD, EPI_DGRAD>(p, st, &si5)));
     si5.ld = cat; si5.off = d.off[4];
@@ -1814,7 +1817,7 @@ int prh_encoder_backward_bf16(const prh_encoder_params* prm, const float* ctx, i
     p.C = f16p(w.dy_cat); p.ldc = cat; p.E1 = f16p(z_cat); p.lde1 = cat; p.es = sv->bn_scale; p.et = sv->bn_shift;
     p.wprep = w.wprep; p.ws_a = w.ws_a; p.ws_b = w.ws_b;
     p.flags = F_MASK | F_STATS;
-    if ((d.off[4] & 63) == 0) p.mask_col0 = d.off[4];      // see prh_encoder_backward: blocks 1..4 are masked later
+    if (g_dgrad_partial && (d.off[4] & 63) == 0) p.mask_col0 = d.off[4];      // see prh_encoder_backward: blocks 1..4 are masked later
     TRY((launch_nt_b16<PRO_NONE, EPI_DGRAD, true, true>(p, st, &si)));
     si.ld = cat; si.off = d.off[4];
   }

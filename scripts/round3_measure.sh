@@ -28,4 +28,9 @@ C)
   bash scripts/pmc_quick.sh r03m/sq_split16 512 1024 && python scripts/pmc_summary.py gpurun_out/r03m/sq_split16 > $O/pmc_sq_lds_l2_B512_split16.txt 2>&1
   tail -30 $O/pmc_sq_lds_l2_B512_split16.txt
   ;;
+D)
+  cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r03m/prof_b32 -- python bench.py --batch 32 --points 2048 --steps 20 --warmup 5 --no-cpu-baseline --no-parity --no-workloads > $O/prof_b32.json 2> $O/prof_b32.err
+  python scripts/summarize_rocprof.py gpurun_out/r03m/prof_b32 $O/r03m_b32 && head -45 $O/r03m_b32_kernel_stats_top40.csv | cut -c1-160
+  ;;
 esac

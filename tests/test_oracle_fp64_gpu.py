@@ -100,3 +100,22 @@ def test_config2_train_step_vs_fp64_oracle_at_size():
     p, out64, loss64, mem64, stats = _oracle_fp64(sd, ctx, noisy, target, "cuda")
     assert maxdiff(memory.detach().reshape(mem64.shape), mem64) < 1e-4
     _check(m, out.detach(), float(loss), p, out64, loss64, stats)
+
+
+def test_config4_rank_share_points_2048_vs_fp64_oracle():
+    """BASELINE config 4's per-rank shape is B=512, N=2048; the same number of points as config 2 fits this
+    check as B=256, N=2048 (N = 2048 keys per cross-attention, 64 key tiles per head): train-mode step
+    against the oracle in fp64, every gradient tensor within 2e-3."""
+    sd = P.linerefine_state_dict(0)
+    ctx, noisy, target = P.synth_batch(256, 2048, 4, 32, seed=4)
+    m = _hip_model(sd)
+    cg, ng = ctx.cuda(), noisy.cuda()
+    memory = m.encode_context(cg)
+    out = m.decode(cg, ng, memory, m.encode_line(ng))
+    from pointnet_refine_amd import ops
+    loss = ops.deep_supervision_l1(out, target.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    p, out64, loss64, mem64, stats = _oracle_fp64(sd, ctx, noisy, target, "cuda")
+    assert maxdiff(memory.detach().reshape(mem64.shape), mem64) < 1e-4
+    _check(m, out.detach(), float(loss), p, out64, loss64, stats)
