@@ -42,6 +42,11 @@ for key, c in data.items():
     ms = c["ms"]
     clk = c.get("GRBM_GUI_ACTIVE", 0) / 8 / (ms * 1e-3) / 1e9 if c.get("GRBM_GUI_ACTIVE") else 0
     wc = c.get("SQ_WAVE_CYCLES", 1)
+    # matrix-pipe utilisation: SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD (MI355X_MICROARCH.md: = 32 x N_mfma for
+    # 32x32x16, 16 x N for 16x16x32); chip-wide busy fraction = that sum / (1024 SIMDs x clock x duration)
+    simd_cycles = 1024.0 * clk * 1e9 * ms * 1e-3 if clk else 0.0
+    mfma_util = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / simd_cycles if simd_cycles else 0.0
+    print(f"   [matrix pipe busy {mfma_util:5.2f} of the SIMD cycles at the held clock; x clock = {mfma_util * clk:4.2f} GHz-equivalent of 2.4]")
     print(f"{key[0][10:52]:42s} grid={key[1]:>9s} {ms:8.3f} ms clk~{clk:4.2f}GHz "
           f"| wave-cycle shares: wait_any {c.get('SQ_WAIT_ANY',0)/wc:5.2f} wait_inst {c.get('SQ_WAIT_INST_ANY',0)/wc:5.2f} "
           f"active {c.get('SQ_ACTIVE_INST_ANY',0)/wc:5.2f} valu {c.get('SQ_ACTIVE_INST_VALU',0)/wc:5.2f} lds {c.get('SQ_ACTIVE_INST_LDS',0)/wc:5.2f} "

@@ -228,8 +228,9 @@ def test_model_bf16_every_gradient_vs_fp64_oracle(bf16_mode):
     (B=8, N=256, train mode, dropout off) - not "no worse than the reference under autocast" on 64-entry
     heads.  Only 2,048 context points stand behind every BatchNorm statistic and every weight gradient
     here, so the figures are far noisier than at the benchmark's 4.19 M points (worst tensor 1.9e-2 there:
-    bench.py's at_init gate); the gates sit ~1.5x above what this mode measures on this fixture (the
-    printed line).  The model-level claim: `out` within 4e-2 rel-L2, half of the tensors within 6e-2."""
+    bench.py's at_init gate).  Measured on this fixture (r03): out rel-L2 2.8e-2; per-tensor gradient rel-L2
+    median 4.3e-2, 90th percentile 0.14, worst 0.22 (decoder_layers.1.self_attn.in_proj_weight); the gates
+    sit ~1.5x above that."""
     from oracle import linerefine_oracle as O
     sd = P.linerefine_state_dict(0)
     m = _model(sd).train()
@@ -253,5 +254,5 @@ def test_model_bf16_every_gradient_vs_fp64_oracle(bf16_mode):
           f"{vals[len(vals) // 2]:.3e}, p90 {vals[int(len(vals) * 0.9)]:.3e}, worst {rels[worst]:.3e} ({worst})")
     assert rel_l2(o64, out) < 4e-2
     assert vals[len(vals) // 2] < 6e-2
-    assert vals[int(len(vals) * 0.9)] < 2.5e-1
-    assert rels[worst] < 1.0, (worst, rels[worst])
+    assert vals[int(len(vals) * 0.9)] < 2.2e-1
+    assert rels[worst] < 3.5e-1, (worst, rels[worst])

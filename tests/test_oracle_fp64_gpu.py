@@ -5,12 +5,13 @@ fp32 evaluations differ by isolated ReLU / arg-max flips - which is why its gate
 Against the oracle run in fp64 there is no such noise on the reference side, so every tensor that
 receives a gradient is held to 2e-3 rel-L2 here:
 
-* on the G2 inputs (B=8, N=256), oracle in fp64 on the host;
+* on the G2 inputs (B=8, N=256), oracle in fp64 on the host (measured worst tensor 1.1e-3, point_mlp.0.weight);
 * at BASELINE config 2's size (B=512, N=1024, train mode): `memory`, the batch statistics / running
   statistics of all nine BatchNorm layers, `out`, the loss and every parameter gradient.  At that size
   the oracle's tensor math (oracle/linerefine_oracle.py, unchanged) is executed in fp64 by stock PyTorch
   on the device - rocBLAS / eager kernels, none of this repo's - because 13 TFLOP of fp64 do not fit a
-  CPU test; it is still the restatement checking the HIP path, not the other way round."""
+  CPU test; it is still the restatement checking the HIP path, not the other way round (measured worst
+  tensor 4.8e-4 at config 2's size, 2.6e-4 at the N=2048 shape)."""
 import re
 
 import pytest
