@@ -800,6 +800,8 @@ class EncoderFn(torch.autograd.Function):
     def _backward_bf16(ctx, d_gfeat, d_fused):
         saved = ctx.saved_tensors
         x, z_cat, z_fus, gate, coef, argmax = saved[:6]
+        if ENCODER_RETAIN_GRAPH:
+            gate = gate.clone()
         p2 = list(saved[6:])
         dev = x.device
         B, N, Cin = x.shape
@@ -834,12 +836,16 @@ class EncoderFn(torch.autograd.Function):
     def backward(ctx, d_gfeat, d_fused):
         if ctx.consumed:
             raise RuntimeError("pointnet_refine_amd encoder: backward through the same graph a second "
-                               "time is not supported (saved activations are consumed in place)")
-        ctx.consumed = True
+                               "time is not supported by default (the saved gate buffer, 4 KB per point, is "
+                               "overwritten by its gradient); call ops.allow_encoder_retain_graph(True) before "
+                               "the first backward to work on a copy instead")
+        ctx.consumed = not ENCODER_RETAIN_GRAPH
         if ctx.bf16:
             return EncoderFn._backward_bf16(ctx, d_gfeat, d_fused)
         saved = ctx.saved_tensors
         x, z_cat, z_fus, gate, coef, argmax = saved[:6]
+        if ENCODER_RETAIN_GRAPH:
+            gate = gate.clone()          # the only saved buffer the backward writes (dG in place)
         p2 = list(saved[6:])
         dev = x.device
         B, N, Cin = x.shape
@@ -872,6 +878,17 @@ class EncoderFn(torch.autograd.Function):
         grads = [_grad_ret(*b_) for b_ in gb]
         grads = [gi.reshape(s) if gi is not None else None for gi, s in zip(grads, ctx.pshapes)]
         return (dx, None, None, None, None, None, *grads)
+
+
+ENCODER_RETAIN_GRAPH = False
+
+
+def allow_encoder_retain_graph(flag: bool = True):
+    """loss.backward(retain_graph=True) followed by a second backward through the same encoder call: the
+    reference allows it (stock autograd keeps every saved tensor intact).  Here the saved gate buffer is
+    overwritten by its gradient to save 17 GB at B=4096; with this switch on, the backward works on a copy."""
+    global ENCODER_RETAIN_GRAPH
+    ENCODER_RETAIN_GRAPH = bool(flag)
 
 
 def encoder(x_pm, params, buffers, want_global: bool, training: bool, momentum: float, eps: float):

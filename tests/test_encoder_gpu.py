@@ -101,6 +101,30 @@ def test_encoder_backward_twice_raises():
         loss.backward()
 
 
+def test_encoder_backward_twice_with_the_retain_switch():
+    """The reference allows loss.backward(retain_graph=True) twice (src/model.py is stock autograd);
+    ops.allow_encoder_retain_graph(True) makes the backward work on a copy of the one buffer it overwrites:
+    the second backward then ADDS the same gradients (autograd accumulation), as with the reference."""
+    from pointnet_refine_amd import ops
+    sd = P.encoder_state_dict(4, 1024, seed=3)
+    m = _encoder(4, sd).train()
+    ctx, _, _ = P.synth_batch(2, 64, 4, 32, seed=1)
+    ops.allow_encoder_retain_graph(True)
+    try:
+        x = ctx.cuda().transpose(2, 1).contiguous().requires_grad_(True)
+        gf, fu = m(x)
+        loss = (fu * fu).sum() + gf.sum()
+        loss.backward(retain_graph=True)
+        g1 = {k: v.grad.clone() for k, v in m.named_parameters()}
+        dx1 = x.grad.clone()
+        loss.backward()
+        for k, v in m.named_parameters():
+            assert maxdiff(v.grad, 2 * g1[k]) <= 1e-6 * float(g1[k].abs().max()) + 1e-12, k
+        assert maxdiff(x.grad, 2 * dx1) <= 1e-6 * float(dx1.abs().max())
+    finally:
+        ops.allow_encoder_retain_graph(False)
+
+
 def test_encoder_channel_mismatch_raises():
     m = _encoder(4, P.encoder_state_dict(4, 1024, seed=3)).eval()
     with pytest.raises(RuntimeError, match="channels"):
