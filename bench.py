@@ -485,6 +485,31 @@ def extra_workloads(dev, lib, headline_mode, budget_s=270.0):
                          "frac": round(flops / ms / 1e9 / peak, 4)},
                 "hbm": {"algorithmic_gbs": round(byts / ms / 1e6, 1), "frac_of_8TBs": round(byts / ms / 1e6 / HBM_PEAK_GBS, 4)}}
 
+    def encoder_train(mode):
+        lib.prh_set_gemm_mode(mode)
+        torch.manual_seed(0)
+        enc = MultiScalePointNetEncoder(4, 1024).to(dev).train()
+        B, N = 4096, 1024
+        ctx, _, _ = synthetic_batch(B, N, dev, seed=1234)
+        up_g = torch.randn(B, 2048, device=dev)
+        up_f = torch.randn(B, N, 1024, device=dev, dtype=torch.bfloat16 if mode == 4 else torch.float32)
+
+        def step():
+            for p_ in enc.parameters():
+                p_.grad = None
+            gf, fu = enc.forward_pointmajor(ctx, True)
+            torch.autograd.backward([gf, fu], [up_g, up_f])
+        torch.cuda.reset_peak_memory_stats(dev)
+        ms = _timed_steps(step, 1, 3, dev)
+        flops = 3.0 * 5_587_584.0 * N * B
+        peak = MODE_INFO[mode][1] / MODE_INFO[mode][0]
+        return {"workload": "MultiScalePointNetEncoder (shared MLP + fusion + gate + max/mean pool) train-mode forward + backward, "
+                            "gradients on global_feat and fused, B=4096, N=1024",
+                "dtype": MODE_INFO[mode][3], "ms": round(ms, 2), "segments_per_s": round(B / ms * 1e3, 1),
+                "mfma": {"achieved_tflops": round(flops / ms / 1e9, 1), "peak": round(peak, 1), "frac": round(flops / ms / 1e9 / peak, 4)},
+                "max_mem_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1)}
+
+    guarded("encoder_train_fwd_bwd", lambda: encoder_train(3))
     guarded("encoder_eval_fused_fp16", lambda: encoder_eval("fp16"))
     guarded("encoder_eval_fused_fp32_accurate", lambda: encoder_eval("fp32"))
 
