@@ -1,6 +1,6 @@
 """Where does the bf16 mode's output error come from?  Train-mode forward on the G2 inputs
 (dropout off) with encoder side / decoder side in different GEMM modes, against the exact-fp32
-cores.  python scripts/bf16_error_budget.py  (on the GPU box)"""
+cores.  python tests/diag_bf16_error_budget.py  (on the GPU box)"""
 import os
 import sys
 

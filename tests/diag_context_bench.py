@@ -2,7 +2,7 @@
 """Row f2 measurement: whole-scene context building (config 5 shape: 100k-point cloud, 4096
 polylines, N=1024, crop radius 0.3 m) on the HIP path, with the CPU oracle (the reference's
 algorithm) timed beside it on a bounded sample of the same lines.
-usage: python scripts/context_bench.py [n_points] [n_lines]"""
+usage: python tests/diag_context_bench.py [n_points] [n_lines]"""
 import os
 import sys
 import time

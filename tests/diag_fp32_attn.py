@@ -1,5 +1,5 @@
 """Where does the mode-0 (exact fp32 cores) gradient of a decoder chunk depend on its batch-mates?
-(scripts/diag_fp32_chunk.py: chunked vs monolithic gradients differ by 5e-4 in mode 0, 6e-6 in mode 3.)
+(tests/diag_fp32_chunk.py: chunked vs monolithic gradients differ by 5e-4 in mode 0, 6e-6 in mode 3.)
 Attention kernel alone, then the decoder alone, segments 0..3 computed inside a batch of 6 and alone."""
 import os
 import sys

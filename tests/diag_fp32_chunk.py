@@ -1,6 +1,6 @@
 """under PRH_GEMM=fp32 the chunked-decoder gradient differed from the monolithic
 one by 4.2e-4 (default cores 5.7e-6).  One process, the product model: which tensors differ, in which
-GEMM mode, and does the forward already differ?  python scripts/diag_fp32_chunk.py  (GPU box)"""
+GEMM mode, and does the forward already differ?  python tests/diag_fp32_chunk.py  (GPU box)"""
 import os
 import sys
 
