@@ -164,9 +164,24 @@ __global__ __launch_bounds__(256) void conv_in_wgrad_b16_kernel(const unsigned s
   long r1 = r0 + rows_per_block;
   r1 = r1 > P ? P : r1;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (long r = r0 + rg; r < r1; r += 4) {
+  // eight rows per trip, their loads issued together (a 2-byte load per lane and row: one row per trip is
+  // latency-bound - 0.96 ms for 0.5 GB at B=4096, profiles/r03m_*bf16_prh_by_grid.csv)
+  long r = r0 + rg;
+  for (; r + 28 < r1; r += 32) {
+    float d[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) d[u] = __uint_as_float((unsigned)dz[(size_t)(r + 4 * u) * lddz + co] << 16);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float* xr = x + (size_t)(r + 4 * u) * C;       // wave-uniform row: broadcast loads
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (c < C) acc[c] = fmaf(d[u], xr[c], acc[c]);
+    }
+  }
+  for (; r < r1; r += 4) {
     const float d = __uint_as_float((unsigned)dz[(size_t)r * lddz + co] << 16);
-    const float* xr = x + (size_t)r * C;       // wave-uniform row: broadcast loads
+    const float* xr = x + (size_t)r * C;
 #pragma unroll
     for (int c = 0; c < 8; ++c)
       if (c < C) acc[c] = fmaf(d, xr[c], acc[c]);
