@@ -293,3 +293,39 @@ def test_default_model_never_takes_a_stock_pytorch_branch():
         odd(torch.randn(2, 32, 192, device="cuda"), torch.randn(2, 64, 192, device="cuda"))
     with pytest.raises(RuntimeError):
         M.PositionalEncoding(in_dim=2, out_dim=256).cuda()(torch.randn(2, 8, 2, device="cuda"))
+
+
+@pytest.mark.parametrize("B,N,M", [(3, 77, 20), (1, 1, 32), (2, 130, 7), (5, 33, 48)])
+def test_ragged_shapes_forward_backward_vs_oracle(B, N, M):
+    """The reference takes any B >= 1, N >= 1 and any number of line points M (src/model.py:181-234; its
+    callers use M = 32).  Odd sizes - N not a multiple of any tile, a single context point, M below and above
+    32 (two query tiles in the attention kernels, 1..2 row tiles in the small GEMM cores) - eval forward and
+    train-mode forward + backward (dropout off) against the oracle."""
+    sd = P.linerefine_state_dict(0)
+    ctx, noisy, target = P.synth_batch(B, N, 4, M, seed=B * 100 + N + M)
+    m = _model(sd).eval()
+    with torch.no_grad():
+        out = m(ctx.cuda(), noisy.cuda())
+        ref = O.linerefine_forward(O.as_params(sd), ctx, noisy)
+    assert out.shape == (6, B, M, 3)
+    assert maxdiff(out, ref) < 1e-4
+    if B * N < 2:
+        with pytest.raises(ValueError):
+            m.train()(ctx.cuda(), noisy.cuda())              # one value per channel: BatchNorm refuses, as the reference does
+        return
+    m = _model(sd).train()
+    _zero_dropout(m)
+    out = m(ctx.cuda(), noisy.cuda())
+    loss = (out - target.cuda().unsqueeze(0)).abs().mean()
+    loss.backward()
+    p = O.as_params(sd, dtype=torch.float64, requires_grad=True)
+    o64 = O.linerefine_forward(p, ctx.double(), noisy.double(), training=True, new_stats={})
+    (o64 - target.double().unsqueeze(0)).abs().mean().backward()
+    assert maxdiff(out, o64) < 2e-4
+    worst = max((rel_l2(p[k].grad, v.grad), k) for k, v in m.named_parameters() if not _pre_bn_bias(k))
+    # 60..240 query rows: ONE ReLU unit whose pre-activation sits inside fp32 noise of zero (fp32 here, fp64 in
+    # the oracle) moves its layer's gradients by 1 / sqrt(rows x active units) ~ 5e-3 (tests/diag_ragged.py: the
+    # same 5.13e-3 on layer 4 in all three GEMM modes, whose query-side arithmetic is identical; 5.36e-3 on
+    # layer 0 only in the modes whose encoder rounds differently) - so the gate here is 1e-2, against 2e-3 at
+    # the fixture and benchmark sizes (tests/test_oracle_fp64_gpu.py)
+    assert worst[0] < 1e-2, worst
