@@ -66,9 +66,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4096, help="segments per GPU per step")
     ap.add_argument("--points", type=int, default=1024, help="context points per segment")
-    ap.add_argument("--decoder-chunk", type=int, default=2048,
-                    help="segments per decoder micro-batch (bounds the decoder's activation memory; "
-                         "results are identical to the unchunked step)")
+    ap.add_argument("--decoder-chunk", type=int, default=4096,
+                    help="segments per decoder micro-batch (bounds the decoder's activation memory; results are "
+                         "identical to the unchunked step).  4096 = one pass at the headline batch: 208 GB peak, "
+                         "2 %% faster than two micro-batches of 2048 (176 GB)")
     ap.add_argument("--gemm", choices=sorted(GEMM_MODES), default=DEFAULT_GEMM,
                     help="GEMM cores for the large GEMMs. split16 = two scaled fp16 planes, 3 MFMA "
                          "products, fp32-level error (default); split = three bf16 planes, 6 products; "
@@ -442,7 +443,7 @@ def extra_workloads(dev, lib, headline_mode, budget_s=270.0):
         out[name]["wall_s"] = round(time.perf_counter() - t0, 2)
         log(f"workload {name}: {out[name]}")
 
-    def train_wl(B, N, mode, steps, warmup, graph=False, parity=False, chunk=2048):
+    def train_wl(B, N, mode, steps, warmup, graph=False, parity=False, chunk=4096):
         lib.prh_set_gemm_mode(mode)
         torch.manual_seed(0)
         model = LineRefineNet().to(dev).train()
