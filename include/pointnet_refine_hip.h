@@ -92,7 +92,8 @@ typedef struct {
 } prh_encoder_saved;
 
 /* Bytes of scratch the encoder entry points need for P = B*N points
- * (backward = 0: prh_encoder_forward only; 1: also prh_encoder_backward). */
+ * (backward = 0: prh_encoder_forward only; 1: also prh_encoder_backward; 2: prh_encoder_backward with
+ * d_fused_scratch = 1, which needs 4 * out_dim bytes per point less). */
 size_t prh_encoder_workspace_bytes(int B, int N, int in_channel, int out_dim, int backward);
 
 /* MultiScalePointNetEncoder.forward, src/model.py:39-62.
@@ -109,9 +110,12 @@ int prh_encoder_forward(const prh_encoder_params* prm, const float* ctx, int B, 
  *   d_fused [B,N,out_dim] or NULL, d_gfeat [B,2*out_dim] or NULL (at least one)
  *   d_ctx   [B,N,C] or NULL
  *   training must equal the forward's flag.
- * The gradient buffers are read only; saved.gate is consumed (overwritten in place). */
+ * d_gfeat is read only; saved.gate is consumed (overwritten in place).  d_fused is read only unless
+ * d_fused_scratch = 1 (needs d_fused != NULL and d_gfeat == NULL - the path LineRefineNet takes): then the
+ * library turns the caller's d_fused buffer into the fusion layer's gradient scratch (dy_f, then dz_f, in place)
+ * instead of carving one from the workspace - 17 GB less at 4.19 M points; its content is undefined afterwards. */
 int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B, int N,
-                         int training, const float* d_fused, const float* d_gfeat,
+                         int training, float* d_fused, const float* d_gfeat, int d_fused_scratch,
                          const prh_encoder_saved* saved, const prh_encoder_grads* grads,
                          float* d_ctx, void* workspace, size_t workspace_bytes, int device,
                          void* stream);

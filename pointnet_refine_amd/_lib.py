@@ -117,7 +117,7 @@ def _bind(lib):
     lib.prh_encoder_forward.argtypes = [C.POINTER(EncoderParams), vp, i, i, i, f, f, vp, vp,
                                         C.POINTER(EncoderSaved), vp, sz, i, vp]
     lib.prh_encoder_backward.restype = i
-    lib.prh_encoder_backward.argtypes = [C.POINTER(EncoderParams), vp, i, i, i, vp, vp,
+    lib.prh_encoder_backward.argtypes = [C.POINTER(EncoderParams), vp, i, i, i, vp, vp, i,
                                          C.POINTER(EncoderSaved), C.POINTER(EncoderGrads), vp, vp,
                                          sz, i, vp]
     lib.prh_encoder_bf16_workspace_bytes.restype = sz

@@ -984,7 +984,7 @@ void mlp_carve(Arena& a, MlpWS& m, int P, const prh_bn_layer* ly, int L) {
   m.dy_cat = a.f((size_t)P * d.off[L]);
 }
 struct EncWS { StackWS w; StackBwdScratch sc; float* fslab; float* fcslab; float* dy_cat; float* dyf; float* dU; float* gsum_a; float* gsum_b; };
-void enc_carve(Arena& a, EncWS& e, int P, const prh_bn_layer* conv, int cat, int od, bool backward) {
+void enc_carve(Arena& a, EncWS& e, int P, const prh_bn_layer* conv, int cat, int od, int backward) {   // 2: no dyf carve
   stack_ws_carve(a, e.w, P, conv, 5, cat > od ? cat : od, od, cat);
   if (!backward) return;
   stack_bwd_scratch_carve(a, e.sc, P, conv, 5, (size_t)od * cat, cat > od ? cat : od);
@@ -993,7 +993,7 @@ void enc_carve(Arena& a, EncWS& e, int P, const prh_bn_layer* conv, int cat, int
   e.fslab = a.f(fs > gs ? fs : gs);
   e.fcslab = a.f(fc > gc ? fc : gc);
   e.dy_cat = a.f((size_t)P * cat);
-  e.dyf = a.f((size_t)P * od);
+  e.dyf = backward == 2 ? nullptr : a.f((size_t)P * od);      // 2: the caller's d_fused buffer serves (d_fused_scratch)
   e.dU = a.f((size_t)P * 64);
   e.gsum_a = a.f(64);
   e.gsum_b = a.f(64);
@@ -1444,7 +1444,7 @@ size_t prh_encoder_workspace_bytes(int B, int N, int in_channel, int out_dim, in
   for (int l = 0; l < 5; ++l) { ly[l].cin = ch[l]; ly[l].cout = ch[l + 1]; }
   const int cat = 64 + 128 + 256 + 512 + out_dim;
   Arena a; EncWS e;
-  enc_carve(a, e, P, ly, cat, out_dim, backward != 0);
+  enc_carve(a, e, P, ly, cat, out_dim, backward);
   return a.off + 256;
 }
 
@@ -1480,7 +1480,7 @@ int prh_encoder_forward(const prh_encoder_params* prm, const float* ctx, int B, 
   const int cat = enc_cat(prm), od = prm->out_dim, C = prm->in_channel;
   Arena a(workspace, workspace_bytes);
   EncWS ews;
-  enc_carve(a, ews, P, prm->conv, cat, od, false);
+  enc_carve(a, ews, P, prm->conv, cat, od, 0);
   if (!a.ok) return fail(PRH_ERR_WORKSPACE, "encoder_forward: workspace too small (%zu bytes)", workspace_bytes);
   StackWS& w = ews.w;
 
@@ -1542,7 +1542,7 @@ int prh_encoder_forward(const prh_encoder_params* prm, const float* ctx, int B, 
 }
 
 int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B, int N,
-                         int training, const float* d_fused, const float* d_gfeat,
+                         int training, float* d_fused, const float* d_gfeat, int d_fused_scratch,
                          const prh_encoder_saved* sv, const prh_encoder_grads* gr, float* d_ctx,
                          void* workspace, size_t workspace_bytes, int device, void* stream) {
   TRY(check_encoder(prm));
@@ -1555,10 +1555,13 @@ int prh_encoder_backward(const prh_encoder_params* prm, const float* ctx, int B,
   const int cat = enc_cat(prm), od = prm->out_dim, C = prm->in_channel;
   Arena a(workspace, workspace_bytes);
   EncWS ews;
-  enc_carve(a, ews, P, prm->conv, cat, od, true);
+  if (d_fused_scratch && (d_fused == nullptr || d_gfeat != nullptr))
+    return fail(PRH_ERR_ARG, "encoder_backward: d_fused_scratch needs d_fused and no d_gfeat");
+  enc_carve(a, ews, P, prm->conv, cat, od, d_fused_scratch ? 2 : 1);
   StackWS& w = ews.w;
   StackBwdScratch& sc = ews.sc;
-  float *fslab = ews.fslab, *fcslab = ews.fcslab, *dy_cat = ews.dy_cat, *dU = ews.dU, *dyf = ews.dyf;
+  // combine_bwd_kernel reads dF[i] and writes dy[i] from the same thread: dy_f may live in the caller's d_fused
+  float *fslab = ews.fslab, *fcslab = ews.fcslab, *dy_cat = ews.dy_cat, *dU = ews.dU, *dyf = d_fused_scratch ? d_fused : ews.dyf;
   float *gsum_a = ews.gsum_a, *gsum_b = ews.gsum_b;
   if (!a.ok) return fail(PRH_ERR_WORKSPACE, "encoder_backward: workspace too small (%zu bytes)", workspace_bytes);
   StackDims d = stack_dims(prm->conv, 5);

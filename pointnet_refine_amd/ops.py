@@ -850,8 +850,14 @@ class EncoderFn(torch.autograd.Function):
         dev = x.device
         B, N, Cin = x.shape
         out_dim = p2[8].shape[0]
+        # the incoming d_fused (LineRefineNet: context_proj's dgrad output, which nobody else holds) becomes the
+        # fusion layer's gradient scratch instead of 4 KB per point of workspace - unless it is a view, the
+        # pooled gradient is there as well, or a second backward was asked for
+        scratch = (d_fused is not None and d_gfeat is None and d_fused.is_contiguous() and not ENCODER_RETAIN_GRAPH
+                   and d_fused.dtype == torch.float32
+                   and (d_fused._base is None or d_fused._base.numel() == d_fused.numel()))     # not a slice of something larger
         if d_fused is not None:
-            d_fused = d_fused.contiguous()       # read only on the library side
+            d_fused = d_fused.contiguous()
         if d_gfeat is not None:
             if not ctx.has_argmax:
                 raise RuntimeError("encoder backward: gradient for global_feat but no argmax saved")
@@ -869,10 +875,10 @@ class EncoderFn(torch.autograd.Function):
         gr.fusion = L.BnLayerGrad(_p(g[20]), _p(g[21]), _p(g[22]), _p(g[23]))
         gr.d_gate_w1, gr.d_gate_b1, gr.d_gate_w2, gr.d_gate_b2 = _p(g[24]), _p(g[25]), _p(g[26]), _p(g[27])
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        nb = L.lib().prh_encoder_workspace_bytes(B, N, Cin, out_dim, 1)
+        nb = L.lib().prh_encoder_workspace_bytes(B, N, Cin, out_dim, 2 if scratch else 1)
         ws = _ws(dev, nb)
         L.check(L.lib().prh_encoder_backward(C.byref(prm), _p(x), B, N, ctx.training, _p(d_fused),
-                                             _p(d_gfeat), C.byref(sv), C.byref(gr), _p(dx), _p(ws),
+                                             _p(d_gfeat), int(scratch), C.byref(sv), C.byref(gr), _p(dx), _p(ws),
                                              ws.numel(), dev.index, _stream(dev)),
                 "prh_encoder_backward")
         grads = [_grad_ret(*b_) for b_ in gb]
