@@ -432,6 +432,206 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_b16_kernel(const NTParams p, c
 }
 
 // ---------------------------------------------------------------------------------------
+// [r03] gemm_nt_b16d_kernel: the same GEMM for a PLAIN bf16 A operand (dgrads, plain Linears of the bf16 mode),
+// BOTH operands by LDS-DMA and a phase-split k-loop (`cdna_hip_programming.md`, "The 256^2 8-phase template"):
+//   * no staging registers, no VALU and no ds_write in the loop: a lane's 16 B of A go from the activation
+//     tensor straight into the swizzled LDS image (the permutation of h2_off is applied to the SOURCE address:
+//     the LDS side of a DMA is lane-linear); every vector-memory instruction of the loop is an LDS-DMA, so ONE
+//     counted s_waitcnt per k-tile is exact;
+//   * the W fragments of a k-tile (4 column blocks x 2 k-halves) are read in phase 0 and stay in registers, so
+//     the W image of tile kt+2 is DMA-ed over tile kt's as soon as both wave rows have passed their phase 0;
+//     A lives in a ring of three 32-KB images: both operands are in flight two k-tiles ahead
+//     (LDS: 2 x 32 KB W + 3 x 32 KB A = 160 KB, the epilogue scratch aliases it);
+//   * the two wave rows (waves 0-3, 4-7: one of each per SIMD) run one barrier apart: while one issues the 16
+//     MFMAs of two row blocks the other reads its next fragments and issues its share of the DMA.
+// Needs K % 64 == 0 (the image of a partial k-tile could not be zero-filled by a DMA), lda % 8 == 0.
+// ---------------------------------------------------------------------------------------
+constexpr int B16D_W = 0;                       // two W stages
+constexpr int B16D_A = 2 * H2_OPER;             // ring of three A images
+constexpr int B16D_LDS = 2 * H2_OPER + 3 * H2_OPER;     // 163840
+
+// Diagnostic build only (-DPRH_STAMP, scripts/diag_b16d_stamps.py; the shipped library has none of it): wave-uniform
+// cycle accumulators per part of the loop, s_memtime deltas taken where lgkmcnt(0) holds anyway, dumped by
+// lane 0 of waves 0 and 4 of ONE workgroup of the fusion dgrad after its epilogue.
+#ifdef PRH_STAMP
+__device__ unsigned* g_prh_stamp = nullptr;
+#define PRH_TICK(slot)                                                     \
+  {                                                                        \
+    const unsigned long long t_now_ = __builtin_amdgcn_s_memtime();        \
+    t_acc[slot] += (unsigned)(t_now_ - t_prev);                            \
+    t_prev = t_now_;                                                       \
+  }
+#else
+#define PRH_TICK(slot)
+#endif
+
+template <int EPI, bool C16>
+__global__ __launch_bounds__(512, 2) void gemm_nt_b16d_kernel(const NTParams p, const char* __restrict__ Wp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef PRH_STAMP
+  unsigned t_acc[24];
+#pragma unroll
+  for (int i = 0; i < 24; ++i) t_acc[i] = 0u;
+  unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+#endif
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, kc = lane >> 4;
+  const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
+  const int wr = __builtin_amdgcn_readfirstlane(wave >> 2);
+  const int vb = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_n = vb % p.tiles_n, tile_m = vb / p.tiles_n;
+  const int m0 = tile_m * 256, n0 = tile_n * 256;
+  const int KT = p.K / B16_BK;
+  if ((p.flags & F_STAGGER) != 0 && blockIdx.x < 256 && (blockIdx.x & 1) != 0) {
+    const int n = __builtin_amdgcn_readfirstlane((KT * 5) >> 3);      // x 4096 cycles: about half a tile
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(64);
+  }
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+  const unsigned lds0 = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)smem);
+  const unsigned wslice = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);     // + image base + piece * 8192
+  // W: the prepared image is the LDS image, piece pc = bytes [pc * 8 KB, +8 KB) of the 32-KB tile
+  const char* wsrc = Wp + (size_t)tile_n * KT * H2_OPER + tid * 16;
+  // A: piece pc = half (pc >> 1), rows (pc & 1) * 128 + wave * 16 + (lane >> 2); the lane's stored chunk
+  // position lane & 3 holds logical chunk (lane & 3) ^ (-(row >> 2) & 3)
+  const char* asrc[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = h * 128 + wave * 16 + (lane >> 2);
+    int gr = m0 + row; gr = gr < p.M ? gr : p.M - 1;
+    const int ch = (lane & 3) ^ (-(row >> 2) & 3);
+    asrc[h] = reinterpret_cast<const char*>(p.A) + ((size_t)gr * p.lda + ch * 8) * 2;
+  }
+  auto dma_a = [&](int kt_, int slot, int pc) {      // pc 0..3
+    const int kq = kt_ < KT ? kt_ : KT - 1;          // beyond K: harmless re-copy
+    glds16(asrc[pc & 1] + (size_t)kq * (B16_BK * 2) + (pc >> 1) * 64, wslice + B16D_A + slot * H2_OPER + pc * 8192);
+  };
+  auto dma_wp = [&](int kt_, int stage, int pc) {
+    const int kq = kt_ < KT ? kt_ : KT - 1;
+    glds16(wsrc + (size_t)kq * H2_OPER + pc * 8192, wslice + B16D_W + stage * H2_OPER + pc * 8192);
+  };
+  const int aoff = h2_off(wm + l15, kc * 8);          // + i * 1024 + hf * H2_PLANE
+  const int woff = h2_off(wn + l15, kc * 8);          // + j * 1024 + hf * H2_PLANE
+  bf16x8 w[2][4], a[2][2];
+
+  auto phase = [&](int kt_, int aslot, int anext, auto mp, auto tail) {
+    constexpr int MP = decltype(mp)::value;
+    constexpr bool TAIL = decltype(tail)::value;
+    const char* ws = smem + B16D_W + (kt_ & 1) * H2_OPER;
+    const char* as = smem + B16D_A + aslot * H2_OPER;
+    __builtin_amdgcn_sched_barrier(0);
+    if (MP == 0) {
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[hf][j] = *reinterpret_cast<const bf16x8*>(ws + woff + j * 1024 + hf * H2_PLANE);
+    }
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[hf][i] = *reinterpret_cast<const bf16x8*>(as + aoff + (2 * MP + i) * 1024 + hf * H2_PLANE);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!TAIL) {
+      dma_a(kt_ + 2, anext, MP);                     // A piece MP of tile kt+2 -> the ring slot tile kt-1 left
+      if (MP == 1) { dma_wp(kt_ + 2, kt_ & 1, 0); dma_wp(kt_ + 2, kt_ & 1, 1); }    // W of tile kt+2 over tile kt's:
+      if (MP == 2) dma_wp(kt_ + 2, kt_ & 1, 2);                                      // both rows are past phase 0
+      if (MP == 3) dma_wp(kt_ + 2, kt_ & 1, 3);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (MP == 3) {      // tile kt+1 (8 pieces issued one k-tile ago, this tile's 8 behind them) has landed
+      if (TAIL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    PRH_TICK(MP * 4 + 0)            // memory phase (reads, DMA issue, waits)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    PRH_TICK(MP * 4 + 1)            // barrier after the memory phase
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[2 * MP + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[hf][i], w[hf][j], acc[2 * MP + i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    PRH_TICK(MP * 4 + 2)            // 16 MFMAs issued
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    PRH_TICK(MP * 4 + 3)            // barrier after the MFMA phase
+  };
+  auto tile = [&](int kt_, int aslot, int anext, auto tail) {
+    phase(kt_, aslot, anext, std::integral_constant<int, 0>{}, tail);
+    phase(kt_, aslot, anext, std::integral_constant<int, 1>{}, tail);
+    phase(kt_, aslot, anext, std::integral_constant<int, 2>{}, tail);
+    phase(kt_, aslot, anext, std::integral_constant<int, 3>{}, tail);
+  };
+
+  // prologue: tiles 0 and 1 (16 pieces); tile 0 has landed when at most 8 are outstanding
+#pragma unroll
+  for (int pc = 0; pc < 4; ++pc) { dma_a(0, 0, pc); dma_wp(0, 0, pc); }
+#pragma unroll
+  for (int pc = 0; pc < 4; ++pc) { dma_a(1, 1, pc); dma_wp(1, 1, pc); }
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __syncthreads();
+  PRH_TICK(16)                                       // prologue
+  if (wr == 1) __builtin_amdgcn_s_barrier();         // the second wave row runs one barrier behind the first
+  int kt = 0, aslot = 0;
+  for (; kt + 2 < KT; ++kt) {
+    const int anext = aslot == 0 ? 2 : aslot - 1;    // (kt + 2) % 3 == (kt - 1) % 3
+    tile(kt, aslot, anext, std::false_type{});
+    aslot = aslot == 2 ? 0 : aslot + 1;
+  }
+  for (; kt < KT; ++kt) {
+    tile(kt, aslot, 0, std::true_type{});
+    aslot = aslot == 2 ? 0 : aslot + 1;
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  PRH_TICK(17)                                       // loop exit
+  bool bias_done = false;
+  if (C16 && (EPI == EPI_BIAS || EPI == EPI_BIAS_STATS)) {
+    const bool plain = EPI == EPI_BIAS_STATS || (p.flags & (F_RESID | F_RELU_OUT)) == 0;
+    if (plain) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wn + j * 16 + l15;
+        const float b = (p.bias != nullptr && col < p.N) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] = bf16_round(acc[i][j][r] + b);
+      }
+      bias_done = true;
+    }
+  }
+  nt_epilogue_vec<EPI, 4, f32x4[8][4], C16>(acc, p, m0 + wm, n0 + wn, tile_m * 2 + (wave >> 2), lane,
+                                            reinterpret_cast<float*>(smem) + wave * (32 * EPI_LDW), bias_done);
+#ifdef PRH_STAMP
+  PRH_TICK(18)                                       // epilogue: instructions issued
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PRH_TICK(19)                                       // its stores acknowledged
+  if (g_prh_stamp != nullptr && p.K == 1024 && p.N == 1984 && blockIdx.x == gridDim.x / 2 + 3 && lane == 0 && (wave & 3) == 0) {
+    unsigned* o = g_prh_stamp + (wave >> 2) * 32;
+#pragma unroll
+    for (int i = 0; i < 24; ++i) o[i] = t_acc[i];
+    o[24] = (unsigned)KT;
+  }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------
 // wgrad, bf16 operands: C[Mo,Ni] = sum_p A[p,Mo] * proB(B)[p,Ni] over this split's rows.
 // k-tile = 32 rows; a row of the 256-column tile is 512 B = 32 lanes x 16 B, so a 512-thread
 // workgroup stages one operand's k-tile with two 16-B loads per thread (rows r and r + 16).

@@ -45,6 +45,9 @@ enum {
                       //   the FFN hidden layer (src/model.py:131: linear2(dropout(activation(linear1(tgt))))) on the
                       //   epilogue that produces it; the decision is a counter hash of (seed, row, column), so no
                       //   mask is stored: the backward reads it off the output (C > 0)
+  F_STAGGER = 512,    // NT cores: the odd workgroups of the first generation (blockIdx < 256) start about half a
+                      //   tile late, so that the epilogues of half the chip (HBM traffic, no MFMA) fall into the main
+                      //   loops of the other half (MFMA, little HBM traffic) instead of all 256 CUs alternating in step
   F_POOL = 128,       // EPI_GATE (vector epilogue): per 128-row wave tile and column, the largest output,
                       //   the tile-local row of its FIRST occurrence and the column sum -> ws_a / ws_c (int
                       //   bits) / ws_b [2*row_tiles][N]: the dual pooling (src/model.py:58-60) rides on the
@@ -269,6 +272,11 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[MT][NT], const NTParam
 // store and for every epilogue operand read (z for the ReLU mask, the old gradient).
 // `scratch` = this wave's 32*68 floats.  Requires N, ldc, lde1 multiples of 4.
 // ---------------------------------------------------------------------------------------
+typedef int v2i_t __attribute__((ext_vector_type(2)));
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+#ifndef PRH_EPI_RB16
+#define PRH_EPI_RB16 8      // 4: the round-2 batching (A/B builds: scripts/ab_epi_rb.sh)
+#endif
 constexpr int EPI_LDW = 68;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -467,79 +475,101 @@ __device__ __forceinline__ void nt_epilogue_vec(ACC& acc, const NTParams& p, int
   const bool pool = EPI == EPI_GATE && (p.flags & F_POOL) != 0;
   float pmx[4] = {-1.f, -1.f, -1.f, -1.f}, psm[4] = {0.f, 0.f, 0.f, 0.f};     // outputs are >= 0
   int pix[4] = {0, 0, 0, 0};
-  // The epilogue operands (z for the ReLU mask / statistics / gate, the old C when
-  // accumulating) are fetched in ONE batch per 32-row block, branch-free (rows and columns
-  // clamped into the tile's valid range; only the store is predicated), so a block exposes a
-  // single memory latency.  With the loads inside the per-row bounds and flag branches the
-  // compiler emitted load -> s_waitcnt vmcnt(0) -> load -> wait -> store for each of the 32
-  // row groups: ~100 serialized round trips per tile.
-  const int col4c = col4 < p.N ? col4 : (p.N - 4);
-  // load bases: a wave tile entirely below the matrix reads (and discards) row 0 instead
-  const char* __restrict__ Cl = mrows > 0 ? Cb : reinterpret_cast<const char*>(p.C);
-  const char* __restrict__ El = mrows > 0 ? Eb : reinterpret_cast<const char*>(p.E1);
+  // The epilogue operands (z for the ReLU mask / statistics / gate, the old C when accumulating) are fetched in
+  // ONE batch per block of rows, software-pipelined one batch deep.  [r03] Every access goes through a BUFFER
+  // resource that spans exactly this wave tile's valid rows: a load beyond them returns 0 and a store is dropped,
+  // so a row group needs no row clamp, no exec-mask branch around its store and no 64-bit address arithmetic (a
+  // lane whose columns lie beyond N carries an out-of-range offset), and the ReLU mask is applied through a
+  // threshold (-inf when the launch has no mask) instead of a flag branch.  In-kernel stamps of the bf16 fusion
+  // dgrad (scripts/diag_b16d_stamps.py) had shown the epilogue at 27-30 k of a tile's 86 k cycles with neither
+  // deeper operand batches (PRH_EPI_RB16) nor staggered workgroups (F_STAGGER) moving it: it is bound by its
+  // own instruction stream (~90 instructions per row group, a third of them branches, s_nop and clamps).
   const bool acc_old = EPI == EPI_DGRAD && accum;
-  // Batches of 4 row groups (two per 32-row block), software-pipelined one deep: batch b+1's
-  // operand loads are issued before batch b is processed.  (Measured against the unpipelined
-  // order on one box: fusion dgrad 49.6 vs 50.0 ms - the wave sharing the SIMD already covers
-  // most of the latency.)
-  constexpr int NB = 2 * MT;
-  float4 zz[2][4], oo[2][4];
-  auto issue = [&](int b, float4 (&z)[4], float4 (&o)[4]) {
-    // pin each batch's loads to its place (the operand pointers are read-only/restrict, so the
-    // bases are laundered through an asm statement; loads hoisted further up spill accumulators)
-    const char* Em = El; const char* Cm = Cl;
-    asm volatile("" : "+s"(Em), "+s"(Cm) : : "memory");
-    int lrc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      z[i] = zero4(); o[i] = zero4();
-      int r = (b >> 1) * 32 + ((b & 1) * 4 + i) * 4 + rr;
-      r = r < mrows ? r : mrows - 1;
-      lrc[i] = r < 0 ? 0 : r;
+  const int vrows = mrows < 0 ? 0 : (mrows > 32 * MT ? 32 * MT : mrows);
+  auto mkrs = [&](const void* base, long ld, int es_, int width) {
+    const long ext = (base != nullptr && vrows > 0) ? ((long)(vrows - 1) * ld + width) * es_ : 0;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)ext, 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t rsC = mkrs(Cb, ldc, ES, p.N);
+  const __amdgpu_buffer_rsrc_t rsE = mkrs(Eb, lde1, ees, rowvec ? 1 : p.N);
+  const __amdgpu_buffer_rsrc_t rsC2 = mkrs(C2b, ldc2, ES, p.N);
+  constexpr int OOB = 0x40000000;                      // beyond every extent, no 32-bit overflow with a row offset added
+  const int vC = c4ok ? col4 * ES : OOB;               // byte offset of the lane's 4 columns in a row of C / C2
+  const int vE = rowvec ? 0 : (c4ok ? col4 * ees : OOB);
+  const int rowC = ldc * ES, rowE = lde1 * ees, rowC2 = ldc2 * ES;
+  const float mthr = mask ? 0.f : -__builtin_huge_valf();
+  constexpr int RB = C16 ? PRH_EPI_RB16 : 4;           // row groups (4 rows each) per batch
+  constexpr int NB = 8 * MT / RB;
+  typedef typename std::conditional<C16, uint2, float4>::type EV;
+  EV zz[2][RB], oo[2][RB];
+  auto ev_zero = [] { EV e; if constexpr (C16) e = make_uint2(0u, 0u); else e = zero4(); return e; };
+  auto ev_load = [](const __amdgpu_buffer_rsrc_t& rs, int off) {
+    EV e;
+    if constexpr (C16) e = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0));
+    else e = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+    return e;
+  };
+  auto ev_f4 = [](const EV& e) {
+    if constexpr (C16) return make_float4(bf16_lo(e.x), bf16_hi(e.x), bf16_lo(e.y), bf16_hi(e.y));
+    else return e;
+  };
+  auto ev_store = [](const __amdgpu_buffer_rsrc_t& rs, int off, const float4& v) {
+    if constexpr (C16) {
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i_t, make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w))), rs, off, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i_t, v), rs, off, 0, 0);
     }
+  };
+  auto issue = [&](int b, EV (&z)[RB], EV (&o)[RB]) {
+#pragma unroll
+    for (int i = 0; i < RB; ++i) { z[i] = ev_zero(); o[i] = ev_zero(); }
     if (need_z) {        // wave-uniform: one batch of loads
       if (rowvec) {
+        if constexpr (!C16) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float s = *reinterpret_cast<const float*>(Em + (size_t)(lrc[i] * lde1) * 4);
-          z[i] = make_float4(s, s, s, s);
+          for (int i = 0; i < RB; ++i) {
+            const float s_ = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsE, ((b * RB + i) * 4 + rr) * rowE, 0, 0));
+            z[i] = make_float4(s_, s_, s_, s_);
+          }
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) z[i] = ld4e<C16>(Em, lrc[i] * lde1 + col4c);
+        for (int i = 0; i < RB; ++i) z[i] = ev_load(rsE, ((b * RB + i) * 4 + rr) * rowE + vE);
       }
     }
     if (acc_old) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = ld4e<C16>(Cm, lrc[i] * ldc + col4c);
+      for (int i = 0; i < RB; ++i) o[i] = ev_load(rsC, ((b * RB + i) * 4 + rr) * rowC + vC);
     }
   };
   issue(0, zz[0], oo[0]);
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
-    const int mt = b >> 1, hb = b & 1;
-    if (b + 1 < NB) issue(b + 1, zz[(b + 1) & 1], oo[(b + 1) & 1]);
-    // accumulator block -> scratch (column layout: conflict-free 128-B rows)
-    if (hb == 0) epi_block_to_scratch(acc, mt, scratch, lane);
+    if (b + 1 < NB) {
+      __builtin_amdgcn_sched_barrier(0);               // the next batch's loads stay in front of this batch's work
+      issue(b + 1, zz[(b + 1) & 1], oo[(b + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     // scratch -> row-major float4 per lane
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int it = hb * 4 + i;
+    for (int i = 0; i < RB; ++i) {
+      const int g = b * RB + i;
+      const int mt = g >> 3, it = g & 7;
+      // accumulator block -> scratch (column layout: conflict-free 128-B rows)
+      if (it == 0) epi_block_to_scratch(acc, mt, scratch, lane);
       const int lrow = it * 4 + rr;
       const int lr = mt * 32 + lrow;
       const bool ok = lr < mrows && c4ok;
       float4 v = *reinterpret_cast<const float4*>(scratch + lrow * EPI_LDW + c4);
       v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
-      const float4 z = zz[b & 1][i];
-      const float4 o = oo[b & 1][i];
+      const float4 z = ev_f4(zz[b & 1][i]);
+      const float4 o = ev_f4(oo[b & 1][i]);
       if (EPI == EPI_DGRAD) {
         v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-        if (mask) {
-          v.x = fmaf(z.x, es4.x, et4.x) > 0.f ? v.x : 0.f;
-          v.y = fmaf(z.y, es4.y, et4.y) > 0.f ? v.y : 0.f;
-          v.z = fmaf(z.z, es4.z, et4.z) > 0.f ? v.z : 0.f;
-          v.w = fmaf(z.w, es4.w, et4.w) > 0.f ? v.w : 0.f;
-        }
+        v.x = fmaf(z.x, es4.x, et4.x) > mthr ? v.x : 0.f;      // es = et = 0 and mthr = -inf without F_MASK
+        v.y = fmaf(z.y, es4.y, et4.y) > mthr ? v.y : 0.f;
+        v.z = fmaf(z.z, es4.z, et4.z) > mthr ? v.z : 0.f;
+        v.w = fmaf(z.w, es4.w, et4.w) > mthr ? v.w : 0.f;
         if (C16) {      // the statistics describe the values the consumers will read back
           v.x = bf16_round(v.x); v.y = bf16_round(v.y); v.z = bf16_round(v.z); v.w = bf16_round(v.w);
         }
@@ -554,7 +584,7 @@ __device__ __forceinline__ void nt_epilogue_vec(ACC& acc, const NTParams& p, int
         m.z = 0.5f + 0.5f / (1.f + __expf(-v.z)); m.w = 0.5f + 0.5f / (1.f + __expf(-v.w));
         v.x = fmaxf(fmaf(z.x, es4.x, et4.x), 0.f) * m.x; v.y = fmaxf(fmaf(z.y, es4.y, et4.y), 0.f) * m.y;
         v.z = fmaxf(fmaf(z.z, es4.z, et4.z), 0.f) * m.z; v.w = fmaxf(fmaf(z.w, es4.w, et4.w), 0.f) * m.w;
-        if (ok && (p.flags & F_STORE_GATE) != 0) st4e<C16>(C2b, lr * ldc2 + col4, m);
+        if ((p.flags & F_STORE_GATE) != 0) ev_store(rsC2, lr * rowC2 + vC, m);
         if (pool && ok) {      // a lane walks its rows in increasing order: strict > keeps the first maximum
           if (C16) { v.x = bf16_round(v.x); v.y = bf16_round(v.y); v.z = bf16_round(v.z); v.w = bf16_round(v.w); }
           const float vv[4] = {v.x, v.y, v.z, v.w};
@@ -577,7 +607,7 @@ __device__ __forceinline__ void nt_epilogue_vec(ACC& acc, const NTParams& p, int
           v.w = epi_keep(dseed, rw, c0 + 3, p.drop_thresh) ? v.w * p.drop_scale : 0.f;
         }
       }
-      if (ok) st4e<C16>(Cb, lr * ldc + col4, v);
+      ev_store(rsC, lr * rowC + vC, v);
     }
     // keep the running column sums here: left alone, the compiler sinks all 64 accumulation
     // steps into the F_STATS branch below and carries every v and z there (32 spilled VGPRs,

@@ -119,7 +119,24 @@ __device__ __forceinline__ void h2_compute(f32x4 (&acc)[8][4], const char* st, i
   }
 }
 
-template <int PRO, int EPI>
+// PP ("ping-pong", [r03]): the same tile, staging and numerics on a phase-split k-loop.  The two wave rows
+// of the workgroup (waves 0-3 and 4-7: one wave of each on every SIMD) run ONE barrier apart: while a row
+// issues the 24 MFMAs of two of its eight row blocks, the other row is in its memory phase (the fragment reads
+// of its next two row blocks, one row pass of the next k-tile's conversion, its share of the loads), then
+// they swap - 8 raw s_barriers per 32-deep k-tile instead of one __syncthreads, no MFMA and no staging
+// instruction of the same wave in the same phase (`cdna_hip_programming.md`, "The 256^2 8-phase template").
+// Hazards: a memory phase ends on lgkmcnt(0) before its barrier (its ds_reads are done before the other row
+// may overwrite the stage, its ds_writes are visible); the W image of tile kt+1 is DMA-ed in phase 0 and
+// awaited (counted vmcnt) before the barrier of phase 3; tile kt+1 is first read two barriers later.
+// Measured (PRH_H2_PP=1, scripts/ab_pp.sh + scripts/pmc_pp.sh, one box each): parity-green on every GEMM / encoder /
+// model / fp64-oracle test; plain-operand launches 3-4 % faster (fusion dgrad 45.8 vs 47.7 ms, K=1536 8.25 vs 8.55),
+// BN+ReLU-prologue launches 3-4 % slower (fusion fwd 42.5 vs 40.9), step 437.5-438.4 vs 437.6-438.5 ms.  The SQ
+// counters say why it cannot matter: the matrix pipe's busy share moves (fusion dgrad 0.57 -> 0.62, fusion fwd 0.59 ->
+// 0.57) and the clock the chip holds moves the other way (1.76 -> 1.70, 1.75 -> 1.83 GHz): busy x clock stays at
+// 1.01-1.05 GHz-equivalent of 2.4 on both loops.  This core runs at the board's power limit for its instruction
+// mix (fp16 MFMA on random mantissas + fp32 operand stream from HBM + split arithmetic); a denser issue stream is
+// paid back in clock (MI355X_MICROARCH.md, "DVFS give-back" item 3).  Off by default.
+template <int PRO, int EPI, bool PP = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_h2_kernel(const NTParams p,
                                                             const char* __restrict__ Wp) {
   static_assert(PRO == PRO_NONE || PRO == PRO_BNRELU || PRO == PRO_GATE1, "prologue not supported");
@@ -253,12 +270,114 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_h2_kernel(const NTParams p,
   __syncthreads();
   // tile 0 was converted out of set 0 above: iteration kt converts tile kt+1 from set (kt+1)&1
   int kt = 0;
-  for (; kt + 2 < KT; kt += 2) {
-    iter(kt, std::integral_constant<int, 1>{}, std::false_type{});
-    iter(kt + 1, std::integral_constant<int, 0>{}, std::false_type{});
+  if constexpr (!PP) {
+    for (; kt + 2 < KT; kt += 2) {
+      iter(kt, std::integral_constant<int, 1>{}, std::false_type{});
+      iter(kt + 1, std::integral_constant<int, 0>{}, std::false_type{});
+    }
+    if (kt < KT) iter(kt, std::integral_constant<int, 1>{}, std::true_type{});
+    if (kt + 1 < KT) iter(kt + 1, std::integral_constant<int, 0>{}, std::true_type{});
+  } else {
+    const int wr = __builtin_amdgcn_readfirstlane(wave >> 2);
+    const int aoff = h2_off(wm + l15, kc * 8);                  // + i * 1024 (+ H2_PLANE): row block i
+    const int woff = H2_OPER + h2_off(wn + l15, kc * 8);        // + j * 1024 (+ H2_PLANE): column block j
+    f16x8 wh[4], wl[4], ah[2], al[2];
+    // one row pass (64 rows x this thread's 4 k-values) of tile kt+1: prologue, scale, split, two 8-B stores
+    auto store_pass = [&](int kt1, char* st, const float4& r_, const int j) {
+      const int k = kt1 * H2_BK + sc;
+      const bool kok = k < p.K || PRO != PRO_NONE;
+      float4 ka = zero4(), kb = zero4();
+      if (PRO != PRO_NONE) {
+        ka = *reinterpret_cast<const float4*>(coef + k);
+        kb = *reinterpret_cast<const float4*>(coef + KP + k);
+      }
+      float4 v;
+      if (PRO == PRO_GATE1) v = pro_apply<PRO>(make_float4(gi[j], 0.f, 0.f, 0.f), zero4(), ka, kb, zero4());
+      else v = pro_apply<PRO>(r_, zero4(), ka, kb, zero4());
+      v.x = kok ? v.x : 0.f; v.y = kok ? v.y : 0.f; v.z = kok ? v.z : 0.f; v.w = kok ? v.w : 0.f;
+      if (PRO == PRO_NONE) { v.x *= sA; v.y *= sA; v.z *= sA; v.w *= sA; }
+      uint2 h, l;
+      split2h(v.x, v.y, h.x, l.x);
+      split2h(v.z, v.w, h.y, l.y);
+      char* q = st + h2_off(sr + 64 * j, sc);
+      *reinterpret_cast<uint2*>(q) = h;
+      *reinterpret_cast<uint2*>(q + H2_PLANE) = l;
+    };
+    auto phase = [&](int kt_, auto mp, auto cs, auto tail) {
+      constexpr int MP = decltype(mp)::value;
+      constexpr int CS = decltype(cs)::value;
+      constexpr bool TAIL = decltype(tail)::value;
+      const char* cur = smem + (kt_ & 1) * H2_STAGE;
+      char* nxt = smem + ((kt_ + 1) & 1) * H2_STAGE;
+      // ---- memory phase MP: fragments of row blocks 2 MP, 2 MP + 1 (and, in phase 0, of the 4 column blocks)
+      __builtin_amdgcn_sched_barrier(0);
+      if (MP == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          wh[j] = *reinterpret_cast<const f16x8*>(cur + woff + j * 1024);
+          wl[j] = *reinterpret_cast<const f16x8*>(cur + woff + j * 1024 + H2_PLANE);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = *reinterpret_cast<const f16x8*>(cur + aoff + (2 * MP + i) * 1024);
+        al[i] = *reinterpret_cast<const f16x8*>(cur + aoff + (2 * MP + i) * 1024 + H2_PLANE);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // row pass MP of tile kt+1 out of register set CS (loaded one k-tile ago)
+      store_pass(kt_ + 1, nxt, ra[CS][MP], MP);
+      __builtin_amdgcn_sched_barrier(0);
+      if (MP == 0) dma_w(kt_ + 1, (kt_ + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!TAIL && PRO != PRO_GATE1)
+        ra[CS ^ 1][MP] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA, voA[MP] + (kt_ + 2) * (H2_BK * 4), 0, 0));
+      __builtin_amdgcn_sched_barrier(0);
+      if (MP == 3) {      // the W image of tile kt+1 (4 DMA pieces of phase 0) has landed; the row passes behind it may fly on
+        if (TAIL || PRO == PRO_GATE1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- MFMA phase MP: 2 row blocks x 4 column blocks x 3 products, product-outer (8 independent accumulators
+      // between two MFMAs on the same one)
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[2 * MP + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], wh[j], acc[2 * MP + i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[2 * MP + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], wl[j], acc[2 * MP + i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[2 * MP + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], wh[j], acc[2 * MP + i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto tile = [&](int kt_, auto cs, auto tail) {
+      phase(kt_, std::integral_constant<int, 0>{}, cs, tail);
+      phase(kt_, std::integral_constant<int, 1>{}, cs, tail);
+      phase(kt_, std::integral_constant<int, 2>{}, cs, tail);
+      phase(kt_, std::integral_constant<int, 3>{}, cs, tail);
+    };
+    if (wr == 1) __builtin_amdgcn_s_barrier();       // the second wave row runs one barrier behind the first
+    for (; kt + 2 < KT; kt += 2) {
+      tile(kt, std::integral_constant<int, 1>{}, std::false_type{});
+      tile(kt + 1, std::integral_constant<int, 0>{}, std::false_type{});
+    }
+    if (kt < KT) tile(kt, std::integral_constant<int, 1>{}, std::true_type{});
+    if (kt + 1 < KT) tile(kt + 1, std::integral_constant<int, 0>{}, std::true_type{});
+    if (wr == 0) __builtin_amdgcn_s_barrier();       // same number of barriers on both rows
   }
-  if (kt < KT) iter(kt, std::integral_constant<int, 1>{}, std::true_type{});
-  if (kt + 1 < KT) iter(kt + 1, std::integral_constant<int, 0>{}, std::true_type{});
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 #pragma unroll

@@ -141,6 +141,8 @@ struct CoreOverride {
 };
 // PRH_H2_GEN=1 keeps the split-fp16 NT GEMMs on the first-generation core (32x32x16 MFMA, BK 16)
 bool g_h2_gen2 = [] { const char* e = getenv("PRH_H2_GEN"); return !(e && strcmp(e, "1") == 0); }();
+// PRH_H2_PP=1: phase-split ("ping-pong") k-loop of the second-generation NT core (prh_gemm_h2.hpp)
+bool g_h2_pp = [] { const char* e = getenv("PRH_H2_PP"); return e && strcmp(e, "1") == 0; }();
 // PRH_TN_TR=0 keeps the split-fp16 wgrads on the column-staged core
 int g_tn_skew = [] { const char* e = getenv("PRH_TN_SKEW"); return e ? atoi(e) : 0; }();   // diagnostic
 // PRH_SMALL=0 keeps the launches the small-problem cores (prh_small.hpp) would take on the 128 x 128 fp32 cores
@@ -234,6 +236,10 @@ static_assert(8 * 32 * EPI_LDW * 4 <= S3_LDS, "epilogue scratch must fit in the 
 // ------------------------------------------------------------------ bf16 mode launchers (prh_b16.hpp)
 // C[M,N] = pro(A) W^T on the bf16 NT core.  A bf16 (A16) or fp32, C / C2 / matrix E1 bf16 (C16)
 // or fp32.  p.wprep must hold b16_weight_bytes(N, K).  Leading dimensions in elements.
+// PRH_STAGGER=1: half of the first generation of workgroups of a large NT launch starts half a tile late
+bool g_stagger = [] { const char* e = getenv("PRH_STAGGER"); return e && strcmp(e, "1") == 0; }();
+// PRH_B16_DMA=0: plain-operand bf16 NT GEMMs stay on the register-staged core (A/B comparison)
+bool g_b16_dma = [] { const char* e = getenv("PRH_B16_DMA"); return !(e && strcmp(e, "0") == 0); }();
 template <int PRO, int EPI, bool A16, bool C16>
 int launch_nt_b16(NTParams& p, hipStream_t st, StatInfo* si = nullptr) {
   if (p.M <= 0 || p.N <= 0) return PRH_OK;
@@ -242,6 +248,7 @@ int launch_nt_b16(NTParams& p, hipStream_t st, StatInfo* si = nullptr) {
       (p.E1 != nullptr && !rowvec && (p.lde1 & 3)) || (p.C2 != nullptr && (p.ldc2 & 3)) || p.wprep == nullptr)
     return fail(PRH_ERR_ARG, "gemm_nt_b16: K %% 8, N %% 4 and aligned leading dimensions required (K=%d N=%d lda=%ld ldc=%ld)",
                 p.K, p.N, p.lda, p.ldc);
+  if (rowvec && C16) return fail(PRH_ERR_ARG, "gemm_nt_b16: a row-vector E1 comes with fp32 outputs");
   const int KT = cdiv(p.K, B16_BK), NTl = cdiv(p.N, 256);
   const size_t lds = (size_t)H2_LDS + (PRO == PRO_NONE ? 0 : 2 * (size_t)(KT + 2) * B16_BK * 4);
   if (lds > 160 * 1024) return fail(PRH_ERR_ARG, "gemm_nt_b16: K=%d too deep for the prologue coefficient image", p.K);
@@ -258,6 +265,19 @@ int launch_nt_b16(NTParams& p, hipStream_t st, StatInfo* si = nullptr) {
   const double by = ea * (double)p.M * p.K * (PRO == PRO_GATE1 ? 0 : 1) +
                     ec * (double)p.M * p.N * (EPI == EPI_GATE ? 3 : (EPI == EPI_DGRAD ? 2 : 1)) + 4.0 * (double)p.N * p.K;
   ProfScope ps(nm, 2.0 * p.M * (double)p.N * p.K, by, st);
+  if constexpr (PRO == PRO_NONE && A16) {
+    // plain bf16 operand: both operands by LDS-DMA, phase-split loop (gemm_nt_b16d_kernel)
+    if (g_b16_dma && (p.K % B16_BK) == 0 && (reinterpret_cast<uintptr_t>(p.A) & 15) == 0) {
+      static const int attr_d = allow_big_lds(gemm_nt_b16d_kernel<EPI, C16>);
+      if (attr_d != PRH_OK) return attr_d;
+      if (g_stagger && (long)NTl * cdiv(p.M, 256) >= 1024) p.flags |= F_STAGGER;
+      hipLaunchKernelGGL((gemm_nt_b16d_kernel<EPI, C16>), dim3((unsigned)(NTl * cdiv(p.M, 256))), dim3(512), (size_t)B16D_LDS, st,
+                         p, (const char*)(p.wprep + S3_WHDR));
+      LAUNCH_CHECK();
+      if (si) { si->count = 2 * cdiv(p.M, 256); si->rows = 128; }
+      return PRH_OK;
+    }
+  }
   hipLaunchKernelGGL((gemm_nt_b16_kernel<PRO, EPI, A16, C16>), dim3((unsigned)(NTl * cdiv(p.M, 256))), dim3(512), lds, st,
                      p, (const char*)(p.wprep + S3_WHDR));
   LAUNCH_CHECK();
@@ -448,10 +468,16 @@ int launch_nt(NTParams& p, hipStream_t st, StatInfo* si = nullptr) {   // p.amax
           if (want_pool) p.flags |= F_POOL;
           static const int attr_h2 = allow_big_lds(gemm_nt_h2_kernel<PRO, EPI>);
           if (attr_h2 != PRH_OK) return attr_h2;
+          static const int attr_h2p = allow_big_lds(gemm_nt_h2_kernel<PRO, EPI, true>);
+          if (attr_h2p != PRH_OK) return attr_h2p;
           snprintf(nm, sizeof(nm), "gemm_nt_h2<%d,%d> K=%d N=%d", PRO, EPI, p.K, p.N);
           ProfScope ps(nm, 2.0 * p.M * (double)p.N * p.K, by, st);
-          hipLaunchKernelGGL((gemm_nt_h2_kernel<PRO, EPI>), dim3((unsigned)(NTl * cdiv(p.M, 256))), dim3(512),
-                             lds, st, p, img);
+          if (g_h2_pp)
+            hipLaunchKernelGGL((gemm_nt_h2_kernel<PRO, EPI, true>), dim3((unsigned)(NTl * cdiv(p.M, 256))), dim3(512),
+                               lds, st, p, img);
+          else
+            hipLaunchKernelGGL((gemm_nt_h2_kernel<PRO, EPI>), dim3((unsigned)(NTl * cdiv(p.M, 256))), dim3(512),
+                               lds, st, p, img);
           LAUNCH_CHECK();
           if (si) { si->count = 2 * cdiv(p.M, S3_BM); si->rows = 128; }
           return PRH_OK;
@@ -2567,3 +2593,11 @@ int prh_test_gemm_tn(const float* a, const float* b, float* c, float* colsum, in
 }
 
 }  // extern "C"
+
+#ifdef PRH_STAMP
+// diagnostic build only: where the stamped kernel dumps its cycle accumulators (2 x 32 unsigned)
+extern "C" int prh_debug_stamp_buffer(void* buf) {
+  unsigned* b = reinterpret_cast<unsigned*>(buf);
+  return hipMemcpyToSymbol(HIP_SYMBOL(prh::g_prh_stamp), &b, sizeof(b)) == hipSuccess ? 0 : -1;
+}
+#endif

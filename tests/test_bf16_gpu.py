@@ -42,7 +42,10 @@ def _bf(t):
     return t.to(torch.bfloat16)
 
 
-@pytest.mark.parametrize("rows,k,n", [(1000, 1024, 256), (4099, 64, 1984), (257, 8, 64), (2048, 1984, 1024), (70000, 256, 1536)])
+# K % 64 == 0: the plain-operand launches run on the DMA + phase-split core (gemm_nt_b16d_kernel: 1, 2, 3, 16 and 31
+# k-tiles, ragged row tiles, N off the 256-column tile); K = 8 / 72 stay on the register-staged core
+@pytest.mark.parametrize("rows,k,n", [(1000, 1024, 256), (4099, 64, 1984), (257, 8, 64), (2048, 1984, 1024), (70000, 256, 1536),
+                                      (515, 128, 264), (300, 192, 72), (1, 64, 64), (777, 72, 128)])
 def test_linear_bf16_kernels_are_exact_on_rounded_operands(bf16_mode, rows, k, n):
     lib = bf16_mode
     g = torch.Generator(device="cuda").manual_seed(rows + k + n)
