@@ -445,6 +445,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_b16_kernel(const NTParams p, c
 //   * the two wave rows (waves 0-3, 4-7: one of each per SIMD) run one barrier apart: while one issues the 16
 //     MFMAs of two row blocks the other reads its next fragments and issues its share of the DMA.
 // Needs K % 64 == 0 (the image of a partial k-tile could not be zero-filled by a DMA), lda % 8 == 0.
+// (Tried on top of this, no change - fusion dgrad 19.8-20.1 vs 19.9-20.0 ms on one box: the W fragments of k-half 1
+// read one k-tile ahead in phase 3, so that no memory phase holds more than 8 fragment reads.)
 // ---------------------------------------------------------------------------------------
 constexpr int B16D_W = 0;                       // two W stages
 constexpr int B16D_A = 2 * H2_OPER;             // ring of three A images
