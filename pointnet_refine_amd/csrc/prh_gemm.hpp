@@ -435,10 +435,208 @@ __device__ __forceinline__ void st4e(char* base, int off, float4 v) {
 
 // C16: C, C2, the accumulated-into C and the matrix-shaped E1 are bf16 buffers (leading
 // dimensions in elements); a row-vector E1 (F_E1_ROWVEC: one fp32 value per row) stays fp32.
+// Round-2 form of the vector epilogue (global loads / stores, clamped rows, flag branches), kept for fp32 storage:
+// with the buffer-addressed form below the split-fp16 launches take the same time (they are power-bound in their
+// k-loops) but the fusion dgrad FETCHES 103-106 GB instead of 87 GB per launch (PMC passes on the same sources,
+// `profiles/r03p_epilogue_experiments.txt`): the shorter epilogue changes how far the workgroups of an XCD drift
+// apart, and with them the re-reads of the 8 MB weight image out of the Infinity Cache.  The bf16-storage launches
+// (k-loops a third as long, not power-bound) take the buffer-addressed form: 42.8 instead of 48.4 GB and 1-4 % less time.
+template <int EPI, int MT, class ACC, bool C16>
+__device__ __forceinline__ void nt_epilogue_vec_r2(ACC& acc, const NTParams& p, int rbase_,
+                                                int cbase, int rb, int lane, float* scratch,
+                                                bool bias_done = false) {     // bias already in acc
+  const int rbase = __builtin_amdgcn_readfirstlane(rbase_);
+  const float* biasp = bias_done ? nullptr : p.bias;
+  constexpr int ES = C16 ? 2 : 4;
+  const bool rowvec = EPI == EPI_DGRAD && (p.flags & F_E1_ROWVEC) != 0;
+  const int ees = (C16 && !rowvec) ? 2 : 4;
+  char* __restrict__ Cb = reinterpret_cast<char*>(p.C) + (size_t)rbase * p.ldc * ES;
+  const char* __restrict__ Eb = p.E1 != nullptr ? reinterpret_cast<const char*>(p.E1) + (size_t)rbase * p.lde1 * ees : nullptr;
+  const int ldc = (int)p.ldc, lde1 = (int)p.lde1;
+  const int mrows = p.M - rbase;
+  const int rr = lane >> 4, c4 = (lane & 15) * 4;     // row-major phase: 4 rows x 16 float4
+  const int col4 = cbase + c4;
+  const bool c4ok = col4 < p.N;
+  float4 bias4 = zero4(), es4 = zero4(), et4 = zero4();
+  if (c4ok) {
+    if (biasp != nullptr) bias4 = ldg4(biasp + col4);
+    if ((EPI == EPI_DGRAD && (p.flags & F_MASK) != 0) || EPI == EPI_GATE) {
+      es4 = ldg4(p.es + col4);
+      et4 = ldg4(p.et + col4);
+    }
+  }
+  char* __restrict__ C2b = (EPI == EPI_GATE && p.C2 != nullptr) ? reinterpret_cast<char*>(p.C2) + (size_t)rbase * p.ldc2 * ES : nullptr;
+  const int ldc2 = (int)p.ldc2;
+
+  // statistics straight from the accumulators (column on the lane): sum, then centred M2
+  if (EPI == EPI_BIAS_STATS) epi_col_stats(acc, p, cbase, mrows, rb, lane, biasp);
+
+  const bool tile_masked = EPI != EPI_DGRAD || cbase >= p.mask_col0;      // wave-uniform (64-column wave tiles)
+  const bool mask = (p.flags & F_MASK) != 0 && tile_masked, accum = (p.flags & F_ACCUM) != 0;
+  const bool stats = EPI == EPI_DGRAD && (p.flags & F_STATS) != 0 && tile_masked;
+  const bool resid = EPI == EPI_BIAS && (p.flags & F_RESID) != 0;
+  const unsigned dseed = (EPI == EPI_BIAS && (p.flags & F_DROPOUT) != 0) ? epi_seed(p) : 0u;
+  const bool need_z = (EPI == EPI_DGRAD && (mask || stats)) || EPI == EPI_GATE || resid;
+  float4 s1 = zero4(), s2 = zero4();
+  const bool pool = EPI == EPI_GATE && (p.flags & F_POOL) != 0;
+  float pmx[4] = {-1.f, -1.f, -1.f, -1.f}, psm[4] = {0.f, 0.f, 0.f, 0.f};     // outputs are >= 0
+  int pix[4] = {0, 0, 0, 0};
+  // The epilogue operands (z for the ReLU mask / statistics / gate, the old C when
+  // accumulating) are fetched in ONE batch per 32-row block, branch-free (rows and columns
+  // clamped into the tile's valid range; only the store is predicated), so a block exposes a
+  // single memory latency.  With the loads inside the per-row bounds and flag branches the
+  // compiler emitted load -> s_waitcnt vmcnt(0) -> load -> wait -> store for each of the 32
+  // row groups: ~100 serialized round trips per tile.
+  const int col4c = col4 < p.N ? col4 : (p.N - 4);
+  // load bases: a wave tile entirely below the matrix reads (and discards) row 0 instead
+  const char* __restrict__ Cl = mrows > 0 ? Cb : reinterpret_cast<const char*>(p.C);
+  const char* __restrict__ El = mrows > 0 ? Eb : reinterpret_cast<const char*>(p.E1);
+  const bool acc_old = EPI == EPI_DGRAD && accum;
+  // Batches of 4 row groups (two per 32-row block), software-pipelined one deep: batch b+1's
+  // operand loads are issued before batch b is processed.  (Measured against the unpipelined
+  // order on one box: fusion dgrad 49.6 vs 50.0 ms - the wave sharing the SIMD already covers
+  // most of the latency.)
+  constexpr int NB = 2 * MT;
+  float4 zz[2][4], oo[2][4];
+  auto issue = [&](int b, float4 (&z)[4], float4 (&o)[4]) {
+    // pin each batch's loads to its place (the operand pointers are read-only/restrict, so the
+    // bases are laundered through an asm statement; loads hoisted further up spill accumulators)
+    const char* Em = El; const char* Cm = Cl;
+    asm volatile("" : "+s"(Em), "+s"(Cm) : : "memory");
+    int lrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      z[i] = zero4(); o[i] = zero4();
+      int r = (b >> 1) * 32 + ((b & 1) * 4 + i) * 4 + rr;
+      r = r < mrows ? r : mrows - 1;
+      lrc[i] = r < 0 ? 0 : r;
+    }
+    if (need_z) {        // wave-uniform: one batch of loads
+      if (rowvec) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float s = *reinterpret_cast<const float*>(Em + (size_t)(lrc[i] * lde1) * 4);
+          z[i] = make_float4(s, s, s, s);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z[i] = ld4e<C16>(Em, lrc[i] * lde1 + col4c);
+      }
+    }
+    if (acc_old) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = ld4e<C16>(Cm, lrc[i] * ldc + col4c);
+    }
+  };
+  issue(0, zz[0], oo[0]);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int mt = b >> 1, hb = b & 1;
+    if (b + 1 < NB) issue(b + 1, zz[(b + 1) & 1], oo[(b + 1) & 1]);
+    // accumulator block -> scratch (column layout: conflict-free 128-B rows)
+    if (hb == 0) epi_block_to_scratch(acc, mt, scratch, lane);
+    // scratch -> row-major float4 per lane
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int it = hb * 4 + i;
+      const int lrow = it * 4 + rr;
+      const int lr = mt * 32 + lrow;
+      const bool ok = lr < mrows && c4ok;
+      float4 v = *reinterpret_cast<const float4*>(scratch + lrow * EPI_LDW + c4);
+      v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+      const float4 z = zz[b & 1][i];
+      const float4 o = oo[b & 1][i];
+      if (EPI == EPI_DGRAD) {
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        if (mask) {
+          v.x = fmaf(z.x, es4.x, et4.x) > 0.f ? v.x : 0.f;
+          v.y = fmaf(z.y, es4.y, et4.y) > 0.f ? v.y : 0.f;
+          v.z = fmaf(z.z, es4.z, et4.z) > 0.f ? v.z : 0.f;
+          v.w = fmaf(z.w, es4.w, et4.w) > 0.f ? v.w : 0.f;
+        }
+        if (C16) {      // the statistics describe the values the consumers will read back
+          v.x = bf16_round(v.x); v.y = bf16_round(v.y); v.z = bf16_round(v.z); v.w = bf16_round(v.w);
+        }
+        const float4 q = ok ? v : zero4();
+        s1.x += q.x; s1.y += q.y; s1.z += q.z; s1.w += q.w;
+        s2.x = fmaf(q.x, z.x, s2.x); s2.y = fmaf(q.y, z.y, s2.y);
+        s2.z = fmaf(q.z, z.z, s2.z); s2.w = fmaf(q.w, z.w, s2.w);
+      } else if (EPI == EPI_GATE) {
+        // F = relu(zf*s+t) * m,  m = 0.5 + 0.5*sigmoid(acc + b)     (src/model.py:51,54-55)
+        float4 m;
+        m.x = 0.5f + 0.5f / (1.f + __expf(-v.x)); m.y = 0.5f + 0.5f / (1.f + __expf(-v.y));
+        m.z = 0.5f + 0.5f / (1.f + __expf(-v.z)); m.w = 0.5f + 0.5f / (1.f + __expf(-v.w));
+        v.x = fmaxf(fmaf(z.x, es4.x, et4.x), 0.f) * m.x; v.y = fmaxf(fmaf(z.y, es4.y, et4.y), 0.f) * m.y;
+        v.z = fmaxf(fmaf(z.z, es4.z, et4.z), 0.f) * m.z; v.w = fmaxf(fmaf(z.w, es4.w, et4.w), 0.f) * m.w;
+        if (ok && (p.flags & F_STORE_GATE) != 0) st4e<C16>(C2b, lr * ldc2 + col4, m);
+        if (pool && ok) {      // a lane walks its rows in increasing order: strict > keeps the first maximum
+          if (C16) { v.x = bf16_round(v.x); v.y = bf16_round(v.y); v.z = bf16_round(v.z); v.w = bf16_round(v.w); }
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (vv[e] > pmx[e]) { pmx[e] = vv[e]; pix[e] = lr; }
+            psm[e] += vv[e];
+          }
+        }
+      } else {
+        if (resid) { v.x += z.x; v.y += z.y; v.z += z.z; v.w += z.w; }
+        if ((p.flags & F_RELU_OUT) != 0) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        if (EPI == EPI_BIAS && (p.flags & F_DROPOUT) != 0) {
+          const unsigned rw = (unsigned)(rbase + lr), c0 = (unsigned)col4;
+          v.x = epi_keep(dseed, rw, c0, p.drop_thresh) ? v.x * p.drop_scale : 0.f;
+          v.y = epi_keep(dseed, rw, c0 + 1, p.drop_thresh) ? v.y * p.drop_scale : 0.f;
+          v.z = epi_keep(dseed, rw, c0 + 2, p.drop_thresh) ? v.z * p.drop_scale : 0.f;
+          v.w = epi_keep(dseed, rw, c0 + 3, p.drop_thresh) ? v.w * p.drop_scale : 0.f;
+        }
+      }
+      if (ok) st4e<C16>(Cb, lr * ldc + col4, v);
+    }
+    // keep the running column sums here: left alone, the compiler sinks all 64 accumulation
+    // steps into the F_STATS branch below and carries every v and z there (32 spilled VGPRs,
+    // 9 GB of scratch writes per fusion-dgrad launch at B=4096)
+    if (EPI == EPI_DGRAD)
+      asm volatile("" : "+v"(s1.x), "+v"(s1.y), "+v"(s1.z), "+v"(s1.w), "+v"(s2.x), "+v"(s2.y), "+v"(s2.z), "+v"(s2.w));
+  }
+  if (pool) {
+    // combine the 4 row groups (lane bits 4, 5): larger value wins, ties go to the smaller row
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int o = 16; o <= 32; o <<= 1) {
+        const float ov = __shfl_xor(pmx[e], o);
+        const int oi = __shfl_xor(pix[e], o);
+        psm[e] += __shfl_xor(psm[e], o);
+        if (ov > pmx[e] || (ov == pmx[e] && oi < pix[e])) { pmx[e] = ov; pix[e] = oi; }
+      }
+    if (lane < 16 && c4ok) {
+      *reinterpret_cast<float4*>(p.ws_a + (size_t)rb * p.N + col4) = make_float4(pmx[0], pmx[1], pmx[2], pmx[3]);
+      *reinterpret_cast<float4*>(p.ws_b + (size_t)rb * p.N + col4) = make_float4(psm[0], psm[1], psm[2], psm[3]);
+      *reinterpret_cast<int4*>(p.ws_c + (size_t)rb * p.N + col4) = make_int4(pix[0], pix[1], pix[2], pix[3]);
+    }
+  }
+  if (stats) {
+    // column sums: reduce over the 4 row groups (lane bits 4,5)
+    s1.x += __shfl_xor(s1.x, 16); s1.y += __shfl_xor(s1.y, 16); s1.z += __shfl_xor(s1.z, 16); s1.w += __shfl_xor(s1.w, 16);
+    s2.x += __shfl_xor(s2.x, 16); s2.y += __shfl_xor(s2.y, 16); s2.z += __shfl_xor(s2.z, 16); s2.w += __shfl_xor(s2.w, 16);
+    s1.x += __shfl_xor(s1.x, 32); s1.y += __shfl_xor(s1.y, 32); s1.z += __shfl_xor(s1.z, 32); s1.w += __shfl_xor(s1.w, 32);
+    s2.x += __shfl_xor(s2.x, 32); s2.y += __shfl_xor(s2.y, 32); s2.z += __shfl_xor(s2.z, 32); s2.w += __shfl_xor(s2.w, 32);
+    if (lane < 16 && c4ok) {
+      *reinterpret_cast<float4*>(p.ws_a + (size_t)rb * p.N + col4) = s1;
+      *reinterpret_cast<float4*>(p.ws_b + (size_t)rb * p.N + col4) = s2;
+    }
+  }
+}
+
 template <int EPI, int MT, class ACC, bool C16 = false>
 __device__ __forceinline__ void nt_epilogue_vec(ACC& acc, const NTParams& p, int rbase_,
                                                 int cbase, int rb, int lane, float* scratch,
                                                 bool bias_done = false) {     // bias already in acc
+  if constexpr (!C16) {
+    nt_epilogue_vec_r2<EPI, MT, ACC, false>(acc, p, rbase_, cbase, rb, lane, scratch, bias_done);
+    return;
+  }
   const int rbase = __builtin_amdgcn_readfirstlane(rbase_);
   const float* biasp = bias_done ? nullptr : p.bias;
   constexpr int ES = C16 ? 2 : 4;
