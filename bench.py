@@ -227,14 +227,16 @@ def pmc_traffic(dname, batch, points, mode):
         tmpl = (f"prh::gemm_tn_b16_kernel<{m.group(5)}>" if m.group(1) == "tn"
                 else f"prh::gemm_nt_b16_kernel<{m.group(4)}, {m.group(5)},")
         cands = [r for r in recs if r["kernel"].startswith(tmpl)]
+        if m.group(1) == "nt" and m.group(4) == "0":      # plain operand: the DMA + phase-split core <EPI, C16>
+            cands += [r for r in recs if r["kernel"].startswith(f"prh::gemm_nt_b16d_kernel<{m.group(5)},")]
     else:
         if m.group(1) == "tn" and m.group(3):      # wgrad core with transposed fragment reads
             tmpl = f"prh::gemm_tn_tr_kernel<{m.group(5)}>"
         elif m.group(1) == "tn":                   # column-staged wgrad core, two fp16 planes
             tmpl = f"prh::gemm_tn_s3_kernel<{m.group(4)}, {m.group(5)}, 2>"
-        else:
-            tmpl = f"prh::gemm_nt_h2_kernel<{m.group(4)}, {m.group(5)}>"
-        cands = [r for r in recs if r["kernel"] == tmpl]
+        else:                                      # <PRO, EPI, PP>: PP = phase-split k-loop (PRH_H2_PP)
+            tmpl = f"prh::gemm_nt_h2_kernel<{m.group(4)}, {m.group(5)},"
+        cands = [r for r in recs if r["kernel"] == tmpl or (tmpl.endswith(",") and r["kernel"].startswith(tmpl))]
     if not cands:
         return None, fn
     r = max(cands, key=lambda r: r["fetch_bytes_largest_launch"])      # the fusion-layer launch
