@@ -452,20 +452,7 @@ constexpr int B16D_W = 0;                       // two W stages
 constexpr int B16D_A = 2 * H2_OPER;             // ring of three A images
 constexpr int B16D_LDS = 2 * H2_OPER + 3 * H2_OPER;     // 163840
 
-// Diagnostic build only (-DPRH_STAMP, scripts/diag_b16d_stamps.py; the shipped library has none of it): wave-uniform
-// cycle accumulators per part of the loop, s_memtime deltas taken where lgkmcnt(0) holds anyway, dumped by
-// lane 0 of waves 0 and 4 of ONE workgroup of the fusion dgrad after its epilogue.
-#ifdef PRH_STAMP
-__device__ unsigned* g_prh_stamp = nullptr;
-#define PRH_TICK(slot)                                                     \
-  {                                                                        \
-    const unsigned long long t_now_ = __builtin_amdgcn_s_memtime();        \
-    t_acc[slot] += (unsigned)(t_now_ - t_prev);                            \
-    t_prev = t_now_;                                                       \
-  }
-#else
-#define PRH_TICK(slot)
-#endif
+// (PRH_TICK: diagnostic build only, prh_gemm.hpp)
 
 template <int EPI, bool C16>
 __global__ __launch_bounds__(512, 2) void gemm_nt_b16d_kernel(const NTParams p, const char* __restrict__ Wp) {

@@ -272,6 +272,20 @@ __device__ __forceinline__ void nt_epilogue(f32x16 (&acc)[MT][NT], const NTParam
 // store and for every epilogue operand read (z for the ReLU mask, the old gradient).
 // `scratch` = this wave's 32*68 floats.  Requires N, ldc, lde1 multiples of 4.
 // ---------------------------------------------------------------------------------------
+// Diagnostic build only (-DPRH_STAMP, scripts/diag_b16d_stamps.py; the shipped library has none of it): wave-uniform
+// cycle accumulators per part of a kernel, s_memtime deltas taken where lgkmcnt(0) holds anyway, dumped by lane 0 of
+// waves 0 and 4 of ONE workgroup of a chosen launch after its epilogue.
+#ifdef PRH_STAMP
+__device__ unsigned* g_prh_stamp = nullptr;
+#define PRH_TICK(slot)                                                     \
+  {                                                                        \
+    const unsigned long long t_now_ = __builtin_amdgcn_s_memtime();        \
+    t_acc[slot] += (unsigned)(t_now_ - t_prev);                            \
+    t_prev = t_now_;                                                       \
+  }
+#else
+#define PRH_TICK(slot)
+#endif
 typedef int v2i_t __attribute__((ext_vector_type(2)));
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 #ifndef PRH_EPI_RB16

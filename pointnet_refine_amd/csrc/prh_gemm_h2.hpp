@@ -141,6 +141,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_h2_kernel(const NTParams p,
                                                             const char* __restrict__ Wp) {
   static_assert(PRO == PRO_NONE || PRO == PRO_BNRELU || PRO == PRO_GATE1, "prologue not supported");
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef PRH_STAMP
+  unsigned t_acc[4] = {0u, 0u, 0u, 0u};
+  unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, kc = lane >> 4;
   const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
@@ -269,6 +273,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_h2_kernel(const NTParams p,
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   // tile 0 was converted out of set 0 above: iteration kt converts tile kt+1 from set (kt+1)&1
+  PRH_TICK(0)                        // prologue
   int kt = 0;
   if constexpr (!PP) {
     for (; kt + 2 < KT; kt += 2) {
@@ -380,6 +385,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_h2_kernel(const NTParams p,
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  PRH_TICK(1)                        // k-loop
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -391,6 +397,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_h2_kernel(const NTParams p,
   else
     nt_epilogue_vec<EPI, 4>(acc, p, m0 + wm, n0 + wn, tile_m * 2 + (wave >> 2), lane,
                             reinterpret_cast<float*>(smem) + wave * (32 * EPI_LDW));
+#ifdef PRH_STAMP
+  PRH_TICK(2)                        // epilogue: instructions issued
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PRH_TICK(3)                        // its stores acknowledged
+  // one workgroup of: fusion dgrad (slot block 0), fusion forward (1), K/V projection forward (2), conv5 forward (3)
+  const int which = (p.K == 1024 && p.N == 1984) ? 0 : (p.K == 1984 && p.N == 1024) ? 1 : (p.K == 256 && p.N == 1536) ? 2 : (p.K == 512 && p.N == 1024) ? 3 : -1;
+  if (g_prh_stamp != nullptr && which >= 0 && blockIdx.x == gridDim.x / 2 + 3 && lane == 0 && (wave & 3) == 0) {
+    unsigned* o = g_prh_stamp + 64 + which * 16 + (wave >> 2) * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = t_acc[i];
+    o[4] = (unsigned)KT;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
