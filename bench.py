@@ -412,7 +412,8 @@ def _timed_steps(fn, warmup, steps, dev):
 
 def extra_workloads(dev, lib, headline_mode, budget_s=270.0):
     """The other BASELINE.json configs under the same clock as the headline, run AFTER its timed
-    region and parity step (rank 0, N=1): config 3 (bf16 training step + per-tensor parity), config 5
+    region and parity step (rank 0, N=1): config 2 (B=512, N=1024 step + per-tensor parity against the exact-fp32 cores),
+    config 3 (bf16 training step + per-tensor parity), config 5
     (whole-scene refinement, fp16 forward), the encoder alone through the single fused kernel (the
     north_star's fused shared MLP + max-pool; both precisions), config 4's per-rank share (B=512,
     N=2048) and the reference's own per-GPU batch (B=32, N=2048; eager and HIP graph).  Each entry
@@ -465,6 +466,7 @@ def extra_workloads(dev, lib, headline_mode, budget_s=270.0):
         return r
 
     guarded("config3_bf16_train_step", lambda: train_wl(4096, 1024, 4, steps=6, warmup=2, parity=True))
+    guarded("config2_B512_N1024_fp32_accurate_step", lambda: train_wl(512, 1024, 3, steps=6, warmup=2, parity=True))
     guarded("config4_per_rank_share_B512_N2048", lambda: train_wl(512, 2048, 3, steps=6, warmup=2))
     guarded("reference_batch_B32_N2048_eager", lambda: train_wl(32, 2048, 3, steps=30, warmup=5, chunk=None))
     guarded("reference_batch_B32_N2048_graph", lambda: train_wl(32, 2048, 3, steps=30, warmup=5, graph=True, chunk=None))
