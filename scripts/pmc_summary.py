@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Join the per-pass counter CSVs of scripts/pmc_encoder.sh by dispatch and print one line
-per large GEMM dispatch.  usage: pmc_summary.py gpurun_out/<dir> [min_ms]"""
+per large GEMM dispatch.  usage: pmc_summary.py gpurun_out/<dir> [min_ms] [name substrings, comma separated]"""
 import collections
 import csv
 import glob
@@ -9,6 +9,7 @@ import sys
 
 d = sys.argv[1]
 min_ms = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+KERNELS = sys.argv[3].split(",") if len(sys.argv) > 3 else ["prh::gemm"]      # kernel-name substrings to report
 # durations from the kernel trace of the first pass, counters keyed by (kernel name, occurrence index)
 data = collections.OrderedDict()
 for pas in sorted(os.listdir(d)):
@@ -37,7 +38,7 @@ for pas in sorted(os.listdir(d)):
             seen[(r["Kernel_Name"], g)] += 1
             data.setdefault(key, {})["ms"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
 for key, c in data.items():
-    if "prh::gemm" not in key[0] or c.get("ms", 0) < min_ms or key[2] != 1:
+    if not any(t in key[0] for t in KERNELS) or c.get("ms", 0) < min_ms or key[2] != (1 if "prh::gemm" in key[0] else 0):
         continue
     ms = c["ms"]
     clk = c.get("GRBM_GUI_ACTIVE", 0) / 8 / (ms * 1e-3) / 1e9 if c.get("GRBM_GUI_ACTIVE") else 0
