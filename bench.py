@@ -285,13 +285,20 @@ def parity_check(step, model, batch, lib, mode, dev, batch_bench=None, vhat=None
             with torch.no_grad():
                 for k, v in model.state_dict().items():
                     v.copy_(snap[k])
-            torch.manual_seed(20240217)
-            step.grads.zero()
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            loss = step.forward_backward(*(batch_bench if (tag == "bench" and batch_bench is not None) else batch))
-            torch.cuda.synchronize(dev)
-            ms[tag] = (time.perf_counter() - t0) * 1e3
+            args_ = batch_bench if (tag == "bench" and batch_bench is not None) else batch
+            # the exact-fp32 cores run here for the first time in the process: one untimed pass takes the
+            # workspace growth and the first-launch costs (7.6 s at B=4096 where the steady state is ~2 s)
+            for rep in range(2 if tag == "exact" else 1):
+                with torch.no_grad():
+                    for k, v in model.state_dict().items():
+                        v.copy_(snap[k])
+                torch.manual_seed(20240217)
+                step.grads.zero()
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                loss = step.forward_backward(*args_)
+                torch.cuda.synchronize(dev)
+                ms[tag] = (time.perf_counter() - t0) * 1e3
             res[tag] = (step.last_out.clone(), step.grads.flat.clone(), float(loss))
             step.last_out = None
             ops.release_workspaces()
