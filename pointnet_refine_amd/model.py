@@ -194,7 +194,9 @@ class DetrTransformerDecoderLayer(nn.Module):
         qk_in = self.with_pos_embed(tgt, query_pos)
         qk = _lin(qk_in, sa.in_proj_weight[:2 * d], sa.in_proj_bias[:2 * d])      # q and k share the input
         vv = _lin(tgt, sa.in_proj_weight[2 * d:], sa.in_proj_bias[2 * d:])
-        o = _attn(qk[..., :d], qk[..., d:], vv, h, sa.dropout if self.training else 0.0)
+        pdrop_sa = sa.dropout if self.training else 0.0
+        seed_sa = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if pdrop_sa > 0.0 else 0
+        o = ops.attention_self_packed(qk, vv, h, pdrop_sa, seed_sa)      # q / k read in place, dq / dk in one buffer
         tgt2 = _lin(o, sa.out_proj.weight, sa.out_proj.bias)
         tgt = _add_norm(tgt, tgt2, self.norm1, self.dropout1, self.training)
         ca = self.cross_attn

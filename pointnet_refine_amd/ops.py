@@ -1203,6 +1203,56 @@ def attention(q, k, v, heads: int, dropout_p: float = 0.0, seed: int = 0):
     return AttentionFn.apply(q, k, v, heads, dropout_p, seed)
 
 
+class SelfAttentionPackedFn(torch.autograd.Function):
+    """Self-attention whose queries and keys are the two halves of ONE projection output qk (B, M, 2C) - the packed
+    in-projection of nn.MultiheadAttention applied to q = k = tgt + pos (src/model.py:104-110).  The kernels take
+    leading dimensions, so the halves are read in place (no .contiguous() copy of the query half) and dq / dk are
+    written as the two halves of ONE gradient buffer: autograd's two slice-backward fills and their sum (3 stock
+    launches and 3 passes over (B, M, 2C) per layer) do not exist."""
+
+    @staticmethod
+    def forward(ctx, qk, v, heads, dropout_p, seed):
+        _req_gpu_f32(qk, "packed query / key")
+        _req_gpu_f32(v, "value")
+        B, M, C2 = qk.shape
+        Cq = C2 // 2
+        if C2 != 2 * heads * 32 or heads % 4 or tuple(v.shape) != (B, M, Cq):
+            raise RuntimeError("pointnet_refine_amd.attention_self_packed: expects qk (B, M, 2C), v (B, M, C), heads of 32 channels")
+        qk = qk.contiguous()
+        v, ldv = _rows_view(v, "value")
+        o = torch.empty((B, M, Cq), dtype=torch.float32, device=qk.device)
+        lse = torch.empty((B, heads, M), dtype=torch.float32, device=qk.device)
+        scale = 1.0 / (32.0 ** 0.5)
+        kp = C.c_void_p(qk.data_ptr() + 4 * Cq)
+        L.check(L.lib().prh_attn_forward(_p(qk), C2, kp, C2, _p(v), ldv, _p(o), Cq, _p(lse), B, M, M, heads, scale,
+                                         float(dropout_p), int(seed) & 0xFFFFFFFF, qk.device.index, _stream(qk.device)),
+                "prh_attn_forward")
+        ctx.save_for_backward(qk, v, o, lse)
+        ctx.cfg = (heads, float(dropout_p), int(seed) & 0xFFFFFFFF, scale, ldv)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qk, v, o, lse = ctx.saved_tensors
+        heads, dropout_p, seed, scale, ldv = ctx.cfg
+        B, M, C2 = qk.shape
+        Cq = C2 // 2
+        do = do.contiguous()
+        dqk = torch.empty_like(qk)
+        dv = torch.empty((B, M, Cq), dtype=torch.float32, device=qk.device)
+        kp = C.c_void_p(qk.data_ptr() + 4 * Cq)
+        dkp = C.c_void_p(dqk.data_ptr() + 4 * Cq)
+        L.check(L.lib().prh_attn_backward_ex(_p(qk), C2, kp, C2, _p(v), ldv, _p(o), Cq, _p(lse), _p(do), Cq,
+                                             _p(dqk), C2, dkp, C2, _p(dv), Cq, B, M, M, heads, scale,
+                                             dropout_p, seed, None, qk.device.index, _stream(qk.device)),
+                "prh_attn_backward")
+        return dqk, dv, None, None, None
+
+
+def attention_self_packed(qk, v, heads: int, dropout_p: float = 0.0, seed: int = 0):
+    return SelfAttentionPackedFn.apply(qk, v, heads, dropout_p, seed)
+
+
 def kv_token(k_all, v_all, block: int):
     """(token, arena) for attention_block(): call once per batched K/V projection pair."""
     arena = GradArena()
