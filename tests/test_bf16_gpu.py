@@ -75,6 +75,31 @@ def test_linear_bf16_kernels_are_exact_on_rounded_operands(bf16_mode, rows, k, n
     assert float((db.double() - dyr.sum(0)).abs().max()) < 1e-4 * float(dyr.sum(0).abs().max()) + 1e-4
 
 
+@pytest.mark.parametrize("rows,k,n", [(4099, 1024, 1984), (70000, 256, 1536), (2048, 1984, 1024)])
+def test_dma_core_is_bitwise_reproducible(bf16_mode, rows, k, n):
+    """Race screen of the DMA + phase-split core (counted vmcnt waits, raw barriers, two wave rows one barrier apart):
+    the same launch twenty times must give the same bits - an LDS image read before its DMA has landed, or overwritten
+    before its last read, shows up as a run that differs."""
+    lib = bf16_mode
+    g = torch.Generator(device="cuda").manual_seed(rows + k)
+    x = _bf(torch.randn(rows, k, device="cuda", generator=g))
+    w = torch.randn(n, k, device="cuda", generator=g) / k ** 0.5
+    b = torch.randn(n, device="cuda", generator=g)
+    nb = lib.prh_linear_bf16_workspace_bytes(rows, k, n, 1)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    first = None
+    for _ in range(20):
+        y = torch.full((rows, n), float("nan"), device="cuda")
+        assert lib.prh_linear_forward_bf16(_p(x), k, _p(w), _p(b), _p(y), rows, k, n, 0, _p(ws), nb, 0, st) == 0
+        if first is None:
+            first = y
+            ref = x.double() @ _bf(w).double().t() + b.double()
+            assert float((y.double() - ref).norm() / ref.norm()) < 2e-6
+        else:
+            assert torch.equal(y, first)
+
+
 def test_generic_linear_in_bf16_mode_runs_on_the_bf16_core(bf16_mode):
     """fp32-storage Linears (decoder) in mode 4: input converted in flight, same one-product core."""
     from pointnet_refine_amd import ops

@@ -83,6 +83,35 @@ def test_gemm_rejects_unaligned_k(lib):
     assert rc == -1 and b"multiples of 4" in lib.prh_last_error()
 
 
+@pytest.mark.parametrize("m,n,k", [(4099, 1984, 1024), (20000, 256, 1536), (3000, 1024, 1984)])
+def test_nt_core_is_bitwise_reproducible(m, n, k):
+    """Race screen of the split-fp16 NT core (LDS-DMA weights behind counted vmcnt waits; with PRH_H2_PP=1 - run by
+    tests/test_kernel_switches_gpu.py - raw barriers and two wave rows one barrier apart): twenty launches, one result."""
+    from pointnet_refine_amd import _lib
+    lib = _lib.lib()
+    old = lib.prh_get_gemm_mode()
+    lib.prh_set_gemm_mode(3)
+    try:
+        g = torch.Generator(device="cuda").manual_seed(m + n + k)
+        a = torch.randn(m, k, device="cuda", generator=g)
+        w = torch.randn(n, k, device="cuda", generator=g)
+        nb = lib.prh_linear_forward_workspace_bytes(m, k, n)
+        ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        first = None
+        for _ in range(20):
+            c = torch.full((m, n), float("nan"), device="cuda")
+            assert lib.prh_test_gemm_nt(_p(a), _p(w), _p(c), m, n, k, _p(ws), nb, 0, st) == 0
+            if first is None:
+                first = c
+                ref = a.double() @ w.double().t()
+                assert float((c.double() - ref).norm() / ref.norm()) < 1e-6
+            else:
+                assert torch.equal(c, first)
+    finally:
+        lib.prh_set_gemm_mode(old)
+
+
 def test_split_core_is_fp32_accurate():
     """The split-bf16 core (3 planes, 6 MFMA products) must match fp64 as closely as the
     exact fp32 MFMA core does: relative L2 error below 1e-6 on a K=1984 contraction with a
